@@ -1,0 +1,304 @@
+// Device-side arithmetic of the wavefront path tracer (gfx950).  Compiled with -ffp-contract=off: the only fused
+// operations are the explicit __fmaf_rn calls, so the floating-point sequence of every intersection test is fixed
+// and a host restatement of it can reproduce hit ids bit for bit.  Division and sqrt are hipcc's default
+// correctly rounded forms.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_api.h"
+
+namespace ptd {
+
+constexpr float kPi = 3.14159265358979323846264338327950288f;   // reference src/common.h:16
+constexpr float kEps = 0.001f;                                   // reference src/common.h:17
+constexpr uint32_t kMinDepth = 3;                                // reference src/render.cu:8
+constexpr uint32_t kMaxDepth = 16;                               // reference src/render.cu:9
+constexpr float kFltMax = 3.402823466e+38f;
+constexpr int kSentinel = 0x76543210;                            // bottom-of-stack marker, never a node index
+constexpr int kMaxTreeDepth = 63;                                // reference src/bvh.cuh:12 (64 entries, one sentinel)
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ f3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ f3 xyz(float4 v) { return {v.x, v.y, v.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return __fmaf_rn(a.z, b.z, __fmaf_rn(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return {__fmaf_rn(a.y, b.z, -(a.z * b.y)), __fmaf_rn(a.z, b.x, -(a.x * b.z)), __fmaf_rn(a.x, b.y, -(a.y * b.x))};
+}
+// reference include/cutil_math.cuh:1187-1191 with the host form of rsqrtf (1/sqrt)
+__device__ __forceinline__ f3 normalize3(f3 v) { float s = 1.0f / sqrtf(dot3(v, v)); return v * s; }
+// reference include/cutil_math.cuh:1289-1292
+__device__ __forceinline__ f3 reflect3(f3 i, f3 n)
+{
+    float k = 2.0f * dot3(n, i);
+    return {__fmaf_rn(-k, n.x, i.x), __fmaf_rn(-k, n.y, i.y), __fmaf_rn(-k, n.z, i.z)};
+}
+
+__device__ __forceinline__ int fi(float f) { return __float_as_int(f); }
+__device__ __forceinline__ float fl(int i) { return __int_as_float(i); }
+
+// ---- scene as the kernels see it ----------------------------------------------------------------------------
+struct DPlane { float4 pos; float4 nrm; float4 mat; uint32_t type; uint32_t pad[3]; };    // 64 B
+struct DSphere { float4 pos_r; float4 mat; uint32_t type; uint32_t pad[3]; };            // 48 B
+
+struct DScene {
+    const float4 *nodes;     // 4 float4 per node: left xy box, right xy box, both z ranges, (left, right, 0, 0)
+    const float4 *tris;      // 4 float4 per triangle: Woop rows z, x, y and (prim id, last-in-leaf flag, 0, 0)
+    const DPlane *planes;
+    const DSphere *spheres;
+    uint32_t num_planes, num_spheres, has_bvh, mesh_type;
+    float4 mesh_mat;
+    const float4 *env;       // [envH][envW] rgb + pdf
+    const uint16_t *marg;    // [envW]
+    const uint16_t *cond;    // [envW*envH]
+    uint32_t envW, envH;
+    pt_camera cam;
+};
+
+struct Hit { float t; uint32_t prim; f3 n; };
+
+// ---- counter-based generator: Philox4x32-10, counter (pixel, sample, bounce*4+stage, block), key = seed ------
+enum { STAGE_CAMERA = 0, STAGE_LOGIC = 1, STAGE_SHADE = 2 };
+
+struct Rng {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    uint32_t b0, b1, b2, b3;
+    int have;
+    __device__ __forceinline__ Rng(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stage, uint32_t s0,
+                                   uint32_t s1)
+        : c0(pixel), c1(sample), c2(bounce * 4u + stage), c3(0), k0(s0), k1(s1), b0(0), b1(0), b2(0), b3(0), have(0)
+    {
+    }
+    __device__ __forceinline__ void refill()
+    {
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; r++) {
+            uint32_t h0 = __umulhi(0xD2511F53u, x0), l0 = 0xD2511F53u * x0;
+            uint32_t h1 = __umulhi(0xCD9E8D57u, x2), l1 = 0xCD9E8D57u * x2;
+            x0 = h1 ^ x1 ^ a; x1 = l1; x2 = h0 ^ x3 ^ b; x3 = l0;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        b0 = x0; b1 = x1; b2 = x2; b3 = x3;
+        c3++;
+        have = 4;
+    }
+    // uniform in (0,1], like curand_uniform
+    __device__ __forceinline__ float next()
+    {
+        if (have == 0) refill();
+        uint32_t x = have == 4 ? b0 : (have == 3 ? b1 : (have == 2 ? b2 : b3));
+        have--;
+        return (float)((x >> 8) + 1u) * (1.0f / 16777216.0f);
+    }
+};
+
+// ---- primitives -----------------------------------------------------------------------------------------------
+// reference src/object.cuh:62-75
+__device__ __forceinline__ void hit_plane(const DPlane &pl, uint32_t idx, f3 o, f3 d, Hit &h)
+{
+    f3 n = xyz(pl.nrm);
+    float det = dot3(d, n);
+    if (det < -kEps || det > kEps) {
+        float t = dot3(xyz(pl.pos) - o, n) / det;
+        if (t > kEps && t < h.t) { h.t = t; h.n = n; h.prim = PT_PRIM_PLANE | idx; }
+    }
+}
+
+// reference src/object.cuh:27-44
+__device__ __forceinline__ void hit_sphere(const DSphere &sp, uint32_t idx, f3 o, f3 d, Hit &h)
+{
+    f3 c = xyz(sp.pos_r);
+    float rad = sp.pos_r.w;
+    f3 op = c - o;
+    float b = dot3(op, d);
+    float disc = __fmaf_rn(rad, rad, __fmaf_rn(b, b, -dot3(op, op)));
+    if (disc > 0) {
+        disc = sqrtf(disc);
+        float t = (b - disc) >= 0 ? (b - disc) : (b + disc);
+        if (t > kEps && t < h.t) {
+            h.t = t;
+            f3 p = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
+            h.n = (p - c) / rad;
+            h.prim = PT_PRIM_SPHERE | idx;
+        }
+    }
+}
+
+// reference src/bvh.cuh:75-88; the integer compares of src/bvh.cuh:18-27 become v_min/max(3)_i32.  nood = -ood with
+// NaNs kept positive so a NaN always compares above every number, as on the reference's hardware.
+__device__ __forceinline__ bool hit_aabb(f3 inv, f3 nood, float x0, float x1, float y0, float y1, float z0, float z1,
+                                         float t_max, float &t0)
+{
+    float lox = __fmaf_rn(x0, inv.x, nood.x);
+    float hix = __fmaf_rn(x1, inv.x, nood.x);
+    float loy = __fmaf_rn(y0, inv.y, nood.y);
+    float hiy = __fmaf_rn(y1, inv.y, nood.y);
+    float loz = __fmaf_rn(z0, inv.z, nood.z);
+    float hiz = __fmaf_rn(z1, inv.z, nood.z);
+    int b = max(max(fi(fminf(lox, hix)), fi(fminf(loy, hiy))), max(min(fi(loz), fi(hiz)), fi(kEps)));
+    int e = min(min(fi(fmaxf(lox, hix)), fi(fmaxf(loy, hiy))), min(max(fi(loz), fi(hiz)), fi(t_max)));
+    t0 = fl(b);
+    return fl(e) >= t0;
+}
+
+// reference src/bvh.cuh:93-120
+__device__ __forceinline__ void hit_triangle(float4 v00, float4 v11, float4 v22, uint32_t prim, f3 o, f3 d, Hit &h)
+{
+    float Oz = __fmaf_rn(-o.z, v00.z, __fmaf_rn(-o.y, v00.y, __fmaf_rn(-o.x, v00.x, v00.w)));
+    float Dz = __fmaf_rn(d.z, v00.z, __fmaf_rn(d.y, v00.y, d.x * v00.x));
+    float invDz = 1.0f / Dz;
+    float t = Oz * invDz;
+    if (t > kEps && t < h.t) {
+        float Ox = __fmaf_rn(o.z, v11.z, __fmaf_rn(o.y, v11.y, __fmaf_rn(o.x, v11.x, v11.w)));
+        float Dx = __fmaf_rn(d.z, v11.z, __fmaf_rn(d.y, v11.y, d.x * v11.x));
+        float u = __fmaf_rn(t, Dx, Ox);
+        if (u >= 0.0f) {
+            float Oy = __fmaf_rn(o.z, v22.z, __fmaf_rn(o.y, v22.y, __fmaf_rn(o.x, v22.x, v22.w)));
+            float Dy = __fmaf_rn(d.z, v22.z, __fmaf_rn(d.y, v22.y, d.x * v22.x));
+            float v = __fmaf_rn(t, Dy, Oy);
+            if (v >= 0.0f && u + v <= 1.0f) {
+                h.t = t;
+                h.n = cross3(xyz(v11), xyz(v22));
+                h.prim = prim;
+            }
+        }
+    }
+}
+
+// ---- environment map --------------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp1(float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); }
+
+// fp32 bilinear fetch with wrap addressing at normalised coordinates (reference src/environment_map.cu:156-162)
+__device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float theta)
+{
+    const int W = (int)sc.envW, H = (int)sc.envH;
+    float x = __fmaf_rn(phi, (float)W, -0.5f);
+    float y = __fmaf_rn(theta, (float)H, -0.5f);
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int ix = (int)fx0, iy = (int)fy0;
+    int x0 = ((ix % W) + W) % W, x1 = (x0 + 1) % W;
+    int y0 = ((iy % H) + H) % H, y1 = (y0 + 1) % H;
+    float4 t00 = sc.env[(size_t)y0 * W + x0], t10 = sc.env[(size_t)y0 * W + x1];
+    float4 t01 = sc.env[(size_t)y1 * W + x0], t11 = sc.env[(size_t)y1 * W + x1];
+    float4 r;
+#define PT_BILERP(c) { float top = __fmaf_rn(fx, t10.c - t00.c, t00.c); float bot = __fmaf_rn(fx, t11.c - t01.c, t01.c); \
+                       r.c = __fmaf_rn(fy, bot - top, top); }
+    PT_BILERP(x) PT_BILERP(y) PT_BILERP(z) PT_BILERP(w)
+#undef PT_BILERP
+    return r;
+}
+
+// reference src/environment_map.cuh:32-37,51-56
+__device__ __forceinline__ float4 env_lookup(const DScene &sc, f3 dir)
+{
+    float phi = __fmaf_rn(atan2f(dir.z, dir.x), 0.5f / kPi, 0.5f);
+    float theta = acosf(clamp1(dir.y)) / kPi;
+    return env_fetch(sc, phi, theta);
+}
+
+// reference src/environment_map.cuh:39-49
+__device__ __forceinline__ f3 env_sample_lights(const DScene &sc, Rng &rng)
+{
+    const uint32_t W = sc.envW, H = sc.envH;
+    float f1 = rng.next() * (float)W - 0.5f;
+    uint32_t i1 = f1 <= 0.0f ? 0u : (uint32_t)f1;
+    if (i1 >= W) i1 = W - 1;
+    uint32_t x = sc.marg[i1];
+    float f2 = rng.next() * (float)H - 0.5f;
+    uint32_t i2 = f2 <= 0.0f ? 0u : (uint32_t)f2;
+    if (i2 >= H) i2 = H - 1;
+    uint32_t y = sc.cond[(size_t)x * H + i2];
+    float phi = 2.0f * (float)x * kPi / (float)W;
+    float theta = (float)y * kPi / (float)H;
+    float sin_t = -sinf(theta);
+    return {sin_t * cosf(phi), -cosf(theta), sin_t * sinf(phi)};
+}
+
+// ---- materials --------------------------------------------------------------------------------------------------
+// reference src/material.cuh:11-24
+__device__ __forceinline__ f3 diffuse_dir(f3 n, Rng &rng)
+{
+    float z = __fmaf_rn(rng.next(), 2.0f, -1.0f);
+    float a = rng.next() * 2.0f * kPi;
+    float r = sqrtf(__fmaf_rn(-z, z, 1.0f));
+    float x = r * cosf(a);
+    float y = r * sinf(a);
+    f3 dir = mk3(x, y, z) + n;
+    if (dir.x < kEps && dir.y < kEps && dir.z < kEps) return n;
+    return normalize3(dir);
+}
+
+// reference src/material.cuh:26-32
+__device__ __forceinline__ f3 refract_dir(f3 v, f3 n, float ref_idx)
+{
+    float cos_t = fminf(dot3(-v, n), 1.0f);
+    f3 perp = mk3(__fmaf_rn(n.x, cos_t, v.x), __fmaf_rn(n.y, cos_t, v.y), __fmaf_rn(n.z, cos_t, v.z)) * ref_idx;
+    float k = -sqrtf(fabsf(1.0f - dot3(perp, perp)));
+    f3 parallel = n * k;
+    return normalize3(perp + parallel);
+}
+
+// reference src/material.cuh:34-39
+__device__ __forceinline__ float schlick(float cos_t, float ref_idx)
+{
+    float r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    return __fmaf_rn(1 - r0, powf(1 - cos_t, 5.0f), r0);
+}
+
+// ---- camera -------------------------------------------------------------------------------------------------------
+// reference src/camera.cuh:39-53 and src/render.cu:114-123
+__device__ __forceinline__ void camera_ray(const pt_camera &c, uint32_t W, uint32_t H, uint32_t x, uint32_t y, Rng &rng,
+                                           f3 &o, f3 &d)
+{
+    float u = (float(x) + rng.next() - .5f) / float(W - 1);
+    float v = (float(y) + rng.next() - .5f) / float(H - 1);
+    f3 bl = ld3(c.bottom_left), right = ld3(c.right), up = ld3(c.up);
+    f3 target = {__fmaf_rn(up.x, v, __fmaf_rn(right.x, u, bl.x)), __fmaf_rn(up.y, v, __fmaf_rn(right.y, u, bl.y)),
+                 __fmaf_rn(up.z, v, __fmaf_rn(right.z, u, bl.z))};
+    if (c.lens_radius < kEps) {
+        o = ld3(c.origin);
+        d = normalize3(target);
+    } else {
+        float rx, ry;
+        do {
+            rx = __fmaf_rn(rng.next(), 2.0f, -1.0f);
+            ry = __fmaf_rn(rng.next(), 2.0f, -1.0f);
+        } while (__fmaf_rn(ry, ry, rx * rx) >= 1);
+        rx *= c.lens_radius;
+        ry *= c.lens_radius;
+        f3 cu = ld3(c.u), cv = ld3(c.v);
+        f3 off = {__fmaf_rn(cv.x, ry, cu.x * rx), __fmaf_rn(cv.y, ry, cu.y * rx), __fmaf_rn(cv.z, ry, cu.z * rx)};
+        o = ld3(c.origin) + off;
+        d = normalize3(target - off);
+    }
+}
+
+// Sample-major enumeration of the film: index r in [0, W*H) -> pixel.  When the film tiles into 8x4 blocks a wave's
+// 64 consecutive indices cover a 16x4 patch, which keeps primary rays of a wave close together.
+__device__ __forceinline__ void pixel_of(uint32_t r, uint32_t W, uint32_t H, uint32_t &x, uint32_t &y)
+{
+    if ((W & 7u) == 0 && (H & 3u) == 0) {
+        uint32_t tile = r >> 5, in = r & 31u, tpr = W >> 3;
+        uint32_t ty = tile / tpr, tx = tile - ty * tpr;
+        x = tx * 8 + (in & 7u);
+        y = ty * 4 + (in >> 3);
+    } else {
+        y = r / W;
+        x = r - y * W;
+    }
+}
+
+}   // namespace ptd

@@ -1,0 +1,985 @@
+// libpt_hip.so: wavefront path tracing on MI355X (gfx950) behind the C ABI of include/pt_api.h.
+//
+// One wavefront iteration advances every live path by one segment:
+//   logic    (terminate on miss / depth limit -> film, Russian roulette, sort survivors into 4 material queues
+//             with one wave-aggregated atomic per material and wave)
+//   shade x4 (one kernel per material reads its queue and writes the continued ray, compacted, into the other
+//             path buffer)
+//   generate (fills the rest of that buffer with new camera paths)
+//   advance  (one thread: rolls the device-side counters over)
+//   extend   (closest hit for every ray of the new buffer)
+// Path state ping-pongs between two SoA buffers, so every state access except the queue gather is a coalesced
+// 16 B-per-lane stream.  All counters live on the device; the host only polls them (lagging) to learn when to stop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_api.h"
+#include "pt_device.h"
+
+using namespace ptd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsDepth = 24;          // traversal stack entries kept in LDS per lane; deeper entries go to global
+constexpr uint32_t kDefaultPool = 1u << 22;
+
+struct PathBuf {
+    float4 *o;      // origin xyz
+    float4 *d;      // direction xyz, w = film pixel index bits
+    float4 *thr;    // throughput rgb, w = sample index | bounce << 27
+    float4 *hit;    // unit normal xyz, w = prim id bits          (written by extend)
+    float *t;       // hit distance, FLT_MAX on a miss            (written by extend)
+};
+
+struct Counters {
+    uint32_t n_in;                  // rays in the current buffer
+    uint32_t q_count[4];            // material queue lengths (diffuse, glossy, mirror, glass)
+    uint32_t pad[3];
+    unsigned long long next_sample; // next global sample index to hand out
+    unsigned long long total_samples;
+    unsigned long long rays_total;
+    unsigned long long paths_total;
+    unsigned long long iter;
+    unsigned long long extend_nonempty;
+    unsigned long long trav[3];     // nodes, triangles, leaves (only with COUNT)
+};
+
+__device__ __forceinline__ int mat_slot(uint32_t type)
+{
+    return type == PT_DIFFUSE ? 0 : (type == PT_GLOSSY ? 1 : (type == PT_MIRROR ? 2 : (type == PT_GLASS ? 3 : 0)));
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// extend: closest hit (reference src/render.cu:11-44, src/bvh.cuh:130-189)
+// --------------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void traverse(const DScene &sc, f3 o, f3 d, Hit &h, int (*stk)[kBlock], int *gstk,
+                                         uint32_t gstride, uint32_t gtid, unsigned long long *cnt3)
+{
+    const int tid = threadIdx.x;
+    f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    f3 ood = {inv.x * o.x, inv.y * o.y, inv.z * o.z};
+    f3 nood = {ood.x != ood.x ? fl(0x7FC00000) : -ood.x, ood.y != ood.y ? fl(0x7FC00000) : -ood.y,
+               ood.z != ood.z ? fl(0x7FC00000) : -ood.z};
+    int sp = 0;
+    int node = 0;
+    uint32_t c_nodes = 0, c_tris = 0, c_leaves = 0;
+
+    auto push = [&](int v) {
+        if (sp < kLdsDepth) stk[sp][tid] = v;
+        else gstk[(size_t)(sp - kLdsDepth) * gstride + gtid] = v;
+        sp++;
+    };
+    auto pop = [&]() -> int {
+        if (sp == 0) return kSentinel;
+        sp--;
+        return sp < kLdsDepth ? stk[sp][tid] : gstk[(size_t)(sp - kLdsDepth) * gstride + gtid];
+    };
+
+    while (node != kSentinel) {
+        while ((unsigned)node < (unsigned)kSentinel) {      // inner node
+            const float4 *np = sc.nodes + (size_t)node * 4;
+            const float4 lxy = np[0], rxy = np[1], z = np[2];
+            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
+            if (COUNT) c_nodes++;
+            float t0l, t0r;
+            bool hl = hit_aabb(inv, nood, lxy.x, lxy.y, lxy.z, lxy.w, z.x, z.y, h.t, t0l);
+            bool hr = hit_aabb(inv, nood, rxy.x, rxy.y, rxy.z, rxy.w, z.z, z.w, h.t, t0r);
+            if (hl || hr) {
+                int far_child = ch.y;
+                node = hl ? ch.x : ch.y;
+                if (hl && hr) {
+                    if (t0r < t0l) { far_child = node; node = ch.y; }
+                    push(far_child);
+                }
+            } else {
+                node = pop();
+            }
+        }
+        while (node < 0) {                                   // leaf: run of triangle records
+            if (COUNT) c_leaves++;
+            const float4 *tp = sc.tris + (size_t)(~node) * 4;
+            for (;;) {
+                const float4 v00 = tp[0], v11 = tp[1], v22 = tp[2];
+                const uint2 meta = *reinterpret_cast<const uint2 *>(tp + 3);
+                if (COUNT && !(meta.y & 2u)) c_tris++;
+                hit_triangle(v00, v11, v22, meta.x, o, d, h);
+                if (meta.y & 1u) break;
+                tp += 4;
+            }
+            node = pop();
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&cnt3[0], (unsigned long long)c_nodes);
+        atomicAdd(&cnt3[1], (unsigned long long)c_tris);
+        atomicAdd(&cnt3[2], (unsigned long long)c_leaves);
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4 *__restrict__ ro,
+                                                   const float4 *__restrict__ rd, const Counters *cnt,
+                                                   uint32_t n_fixed, float4 *__restrict__ hit_out,
+                                                   float *__restrict__ t_out, int *gstk, unsigned long long *cnt3)
+{
+    __shared__ int stk[kLdsDepth][kBlock];
+    const uint32_t n = cnt ? cnt->n_in : n_fixed;
+    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
+    for (uint32_t i = gtid; i < n; i += stride) {
+        const float4 o4 = ro[i], d4 = rd[i];
+        const f3 o = xyz(o4), d = xyz(d4);
+        Hit h;
+        h.t = kFltMax; h.prim = PT_PRIM_MISS; h.n = mk3(0, 0, 0);
+        for (uint32_t k = 0; k < sc.num_planes; k++) hit_plane(sc.planes[k], k, o, d, h);
+        for (uint32_t k = 0; k < sc.num_spheres; k++) hit_sphere(sc.spheres[k], k, o, d, h);
+        if (sc.has_bvh) traverse<COUNT>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
+        f3 nn = h.prim == PT_PRIM_MISS ? mk3(0, 0, 0) : normalize3(h.n);     // reference src/render.cu:41
+        hit_out[i] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(h.prim));
+        t_out[i] = h.t;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// logic: reference src/render.cu:49-89
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t material_type_of(const DScene &sc, uint32_t prim)
+{
+    if (prim & PT_PRIM_PLANE) return sc.planes[prim & 0x3FFFFFFFu].type;
+    if (prim & PT_PRIM_SPHERE) return sc.spheres[prim & 0x3FFFFFFFu].type;
+    return sc.mesh_type;
+}
+__device__ __forceinline__ float4 material_of(const DScene &sc, uint32_t prim)
+{
+    if (prim & PT_PRIM_PLANE) return sc.planes[prim & 0x3FFFFFFFu].mat;
+    if (prim & PT_PRIM_SPHERE) return sc.spheres[prim & 0x3FFFFFFFu].mat;
+    return sc.mesh_mat;
+}
+
+__global__ __launch_bounds__(kBlock) void k_logic(DScene sc, PathBuf A, Counters *cnt, uint32_t *__restrict__ queues,
+                                                  uint32_t P, float *__restrict__ film, float spp_total,
+                                                  uint32_t seed0, uint32_t seed1)
+{
+    const uint32_t n = cnt->n_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + lane;
+        int slot = -1;
+        if (i < n) {
+            const float t = A.t[i];
+            const float4 d4 = A.d[i];
+            float4 th = A.thr[i];
+            const uint32_t pixel = __float_as_uint(d4.w);
+            const uint32_t sk = __float_as_uint(th.w);
+            const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+            if (t == kFltMax || 2 * k >= kMaxDepth) {
+                // miss or depth limit: throughput * env(direction) / spp goes to the film (src/render.cu:62-72)
+                const float4 e = env_lookup(sc, xyz(d4));
+                float *px = film + 3 * (size_t)pixel;
+                unsafeAtomicAdd(px + 0, th.x * e.x / spp_total);
+                unsafeAtomicAdd(px + 1, th.y * e.y / spp_total);
+                unsafeAtomicAdd(px + 2, th.z * e.z / spp_total);
+            } else {
+                bool alive = true;
+                if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+                    Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+                    const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+                    if (rng.next() > p) {
+                        alive = false;
+                    } else {
+                        const float ip = 1 / p;
+                        th.x *= ip; th.y *= ip; th.z *= ip;
+                        A.thr[i] = th;
+                    }
+                }
+                if (alive) slot = mat_slot(material_type_of(sc, __float_as_uint(A.hit[i].w)));
+            }
+        }
+        // wave-aggregated queue append: one atomic per material and wave
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const bool mine = slot == m;
+            const unsigned long long mask = __ballot(mine);
+            if (mask) {
+                const uint32_t prefix =
+                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                const int leader = __ffsll((long long)mask) - 1;
+                uint32_t pos = 0;
+                if ((int)lane == leader) pos = atomicAdd(&cnt->q_count[m], (uint32_t)__popcll(mask));
+                pos = __shfl(pos, leader);
+                if (mine) queues[(size_t)m * P + pos + prefix] = i;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// shade: reference src/render.cu:129-242, one kernel per material queue
+// --------------------------------------------------------------------------------------------------------------
+template <int MAT>
+__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PathBuf A, PathBuf B, const Counters *cnt,
+                                                  const uint32_t *__restrict__ queues, uint32_t P, uint32_t seed0,
+                                                  uint32_t seed1)
+{
+    const uint32_t n = cnt->q_count[MAT];
+    uint32_t off = 0;
+#pragma unroll
+    for (int m = 0; m < MAT; m++) off += cnt->q_count[m];
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+        const uint32_t i = queues[(size_t)MAT * P + j];
+        const float4 o4 = A.o[i], d4 = A.d[i], h4 = A.hit[i];
+        float4 th = A.thr[i];
+        const float t = A.t[i];
+        const uint32_t pixel = __float_as_uint(d4.w);
+        const uint32_t sk = __float_as_uint(th.w);
+        const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+        const uint32_t prim = __float_as_uint(h4.w);
+        const float4 mat = material_of(sc, prim);
+        const f3 o = xyz(o4), d = xyz(d4), n3 = xyz(h4);
+        const f3 hitp = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
+        Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
+        f3 out;
+        bool lambert = false;
+        if (MAT == 2) {                                     // mirror (src/render.cu:195-211)
+            out = reflect3(d, n3);
+            th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
+        } else if (MAT == 3) {                              // glass (src/render.cu:213-242)
+            const bool external = dot3(d, n3) < 0;
+            const f3 nn = external ? n3 : -n3;
+            const float ref_idx = external ? (1 / mat.w) : mat.w;
+            const float cos_t = fminf(dot3(-d, nn), 1.0f);
+            const float sin_t = sqrtf(__fmaf_rn(-cos_t, cos_t, 1.0f));
+            if (ref_idx * sin_t > 1.0f || schlick(cos_t, ref_idx) > rng.next()) out = reflect3(d, nn);
+            else out = refract_dir(d, nn, ref_idx);
+            th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
+        } else if (MAT == 1) {                              // glossy (src/render.cu:164-193)
+            if (rng.next() < 0.05f) out = reflect3(d, n3);  // throughput untouched
+            else lambert = true;
+        } else {
+            lambert = true;                                 // Lambertian (src/render.cu:129-162)
+        }
+        if (lambert) {
+            out = (rng.next() < 0.5f) ? diffuse_dir(n3, rng) : env_sample_lights(sc, rng);
+            const float env_pdf = env_lookup(sc, out).w;
+            const float diff_pdf = fmaxf(dot3(n3, out) / kPi, 0.0f);
+            const float mixed_pdf = (env_pdf + diff_pdf) * 0.5f;
+            const float s = diff_pdf / mixed_pdf;
+            th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
+        }
+        th.w = __uint_as_float(sample | ((k + 1) << 27));
+        const uint32_t dst = off + j;
+        B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
+        B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
+        B.thr[dst] = th;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// generate: reference src/render.cu:93-127
+// --------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void new_take(const Counters *cnt, uint32_t P, uint32_t &n_out, uint32_t &take)
+{
+    n_out = cnt->q_count[0] + cnt->q_count[1] + cnt->q_count[2] + cnt->q_count[3];
+    const unsigned long long remaining = cnt->total_samples - cnt->next_sample;
+    const unsigned long long room = P - n_out;
+    take = (uint32_t)(remaining < room ? remaining : room);
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const Counters *cnt, uint32_t P, uint32_t W,
+                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1)
+{
+    uint32_t n_out, take;
+    new_take(cnt, P, n_out, take);
+    const unsigned long long first = cnt->next_sample;
+    const uint32_t npix = W * H;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < take; j += stride) {
+        const unsigned long long g = first + j;
+        const uint32_t s_local = (uint32_t)(g / npix);
+        const uint32_t r = (uint32_t)(g - (unsigned long long)s_local * npix);
+        const uint32_t sample = spp_begin + s_local;
+        uint32_t x, y;
+        pixel_of(r, W, H, x, y);
+        const uint32_t pixel = (H - y - 1) * W + x;
+        Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
+        f3 o, d;
+        camera_ray(sc.cam, W, H, x, y, rng, o, d);
+        const uint32_t dst = n_out + j;
+        B.o[dst] = make_float4(o.x, o.y, o.z, 0.0f);
+        B.d[dst] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
+        B.thr[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+    }
+}
+
+__global__ void k_advance(Counters *cnt, uint32_t P)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t n_out, take;
+    new_take(cnt, P, n_out, take);
+    const uint32_t n_in = n_out + take;
+    cnt->n_in = n_in;
+    cnt->next_sample += take;
+    cnt->paths_total += take;
+    cnt->rays_total += n_in;
+    cnt->iter += 1;
+    if (n_in) cnt->extend_nonempty += 1;
+    cnt->q_count[0] = cnt->q_count[1] = cnt->q_count[2] = cnt->q_count[3] = 0;
+}
+
+// camera rays of one sample index in film-pixel order (parity check of the generate stage)
+__global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, uint32_t sample, uint32_t seed0,
+                                                    uint32_t seed1, float4 *__restrict__ ro, float4 *__restrict__ rd)
+{
+    const uint32_t npix = W * H;
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < npix; r += gridDim.x * kBlock) {
+        uint32_t x, y;
+        pixel_of(r, W, H, x, y);
+        const uint32_t pixel = (H - y - 1) * W + x;
+        Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
+        f3 o, d;
+        camera_ray(sc.cam, W, H, x, y, rng, o, d);
+        ro[pixel] = make_float4(o.x, o.y, o.z, 0.0f);
+        rd[pixel] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+}
+
+}   // namespace
+
+// ================================================================================================================
+// host side
+// ================================================================================================================
+struct pt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cus = 256;
+
+    // scene
+    bool have_scene = false;
+    DScene sc{};
+    std::vector<void *> scene_allocs;
+
+    // options
+    uint32_t pool = kDefaultPool;
+    bool count_traversal = false;
+    bool time_extend = true;
+
+    // film
+    float *film = nullptr;
+    bool film_owned = false;
+    uint32_t W = 0, H = 0;
+
+    // wavefront state
+    uint32_t pool_alloc = 0;
+    PathBuf buf[2]{};
+    uint32_t *queues = nullptr;
+    Counters *cnt = nullptr;
+    Counters *h_cnt = nullptr;     // pinned, 4 slots
+    int *gstk = nullptr;
+    size_t gstk_threads = 0;
+    std::vector<hipEvent_t> events;
+    hipEvent_t poll_ev[4]{};
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(pt_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                                         \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static int extend_grid(const pt_ctx *ctx, uint64_t n)
+{
+    // LDS (24 KB per block) admits 6 blocks of 256 threads per CU
+    const uint64_t cap = (uint64_t)ctx->num_cus * 6;
+    const uint64_t need = (n + kBlock - 1) / kBlock;
+    return (int)std::max<uint64_t>(1, std::min(cap, need));
+}
+static int stream_grid(const pt_ctx *ctx, uint64_t n)
+{
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    const uint64_t need = (n + kBlock - 1) / kBlock;
+    return (int)std::max<uint64_t>(1, std::min(cap, need));
+}
+
+static int ensure_gstk(pt_ctx *ctx)
+{
+    const size_t threads = (size_t)ctx->num_cus * 6 * kBlock;
+    if (ctx->gstk && ctx->gstk_threads == threads) return PT_OK;
+    if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; }
+    HIPCHK(ctx, hipMalloc(&ctx->gstk, threads * (size_t)(kMaxTreeDepth + 1 - kLdsDepth) * sizeof(int)));
+    ctx->gstk_threads = threads;
+    return PT_OK;
+}
+
+static void free_pool(pt_ctx *ctx)
+{
+    for (auto &b : ctx->buf) {
+        (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hit); (void)hipFree(b.t);
+        b = PathBuf{};
+    }
+    (void)hipFree(ctx->queues);
+    ctx->queues = nullptr;
+    ctx->pool_alloc = 0;
+}
+
+static int ensure_pool(pt_ctx *ctx)
+{
+    if (ctx->pool_alloc == ctx->pool) return PT_OK;
+    free_pool(ctx);
+    const size_t P = ctx->pool;
+    for (auto &b : ctx->buf) {
+        HIPCHK(ctx, hipMalloc(&b.o, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.d, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.thr, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.hit, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->queues, 4 * P * sizeof(uint32_t)));
+    ctx->pool_alloc = ctx->pool;
+    return PT_OK;
+}
+
+static void free_scene(pt_ctx *ctx)
+{
+    for (void *p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->have_scene = false;
+    ctx->sc = DScene{};
+}
+
+template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const T **dptr, size_t pad_elems = 0)
+{
+    T *d = nullptr;
+    const size_t n = std::max<size_t>(1, v.size() + pad_elems);
+    HIPCHK(ctx, hipMalloc(&d, n * sizeof(T)));
+    ctx->scene_allocs.push_back(d);
+    HIPCHK(ctx, hipMemset(d, 0, n * sizeof(T)));
+    if (!v.empty()) HIPCHK(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = d;
+    return PT_OK;
+}
+
+extern "C" {
+
+int pt_ctx_create(int device, pt_ctx **out)
+{
+    if (!out) return fail(nullptr, PT_ERR_ARG, "pt_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PT_ERR_HIP, "pt_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, PT_ERR_ARG, "pt_ctx_create: device %d of %d", device, ndev);
+    pt_ctx *ctx = new pt_ctx();
+    ctx->device = device;
+#define CREATECHK(call)                                                                           \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            fail(nullptr, PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));            \
+            delete ctx;                                                                           \
+            return PT_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+    CREATECHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATECHK(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATECHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATECHK(hipMalloc(&ctx->cnt, sizeof(Counters)));
+    CREATECHK(hipHostMalloc(&ctx->h_cnt, 4 * sizeof(Counters)));
+    for (auto &ev : ctx->poll_ev) CREATECHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CREATECHK(hipEventCreate(&ctx->ev_begin));
+    CREATECHK(hipEventCreate(&ctx->ev_end));
+#undef CREATECHK
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_ctx_destroy(pt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_pool(ctx);
+    if (ctx->film_owned) (void)hipFree(ctx->film);
+    (void)hipFree(ctx->cnt);
+    (void)hipHostFree(ctx->h_cnt);
+    (void)hipFree(ctx->gstk);
+    for (auto ev : ctx->events) (void)hipEventDestroy(ev);
+    for (auto ev : ctx->poll_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+void *pt_stream(pt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
+{
+    if (!ctx) return PT_ERR_ARG;
+    switch (option) {
+    case PT_OPT_POOL_SIZE:
+        if (value < 1024 || value > (1ull << 28)) return fail(ctx, PT_ERR_ARG, "pool size %llu out of [1024, 2^28]",
+                                                              (unsigned long long)value);
+        ctx->pool = (uint32_t)value;
+        return PT_OK;
+    case PT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return PT_OK;
+    case PT_OPT_TIME_EXTEND: ctx->time_extend = value != 0; return PT_OK;
+    default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
+    }
+}
+
+int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
+{
+    if (!ctx || !s) return PT_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    DScene sc{};
+
+    // ---- mesh: re-lay the reference's node + float4-run buffers into 64 B node / 64 B triangle records ----------
+    std::vector<float4> nodes, recs;
+    if (s->bvh_nodes && s->num_nodes > 0) {
+        if (!s->bvh_tris || s->num_tri_float4 < 2) return fail(ctx, PT_ERR_ARG, "mesh without triangle buffer");
+        if (s->num_nodes >= (uint64_t)kSentinel || s->num_tri_float4 >= (1ull << 31))
+            return fail(ctx, PT_ERR_ARG, "mesh too large for 31-bit node/triangle references");
+        const uint64_t N = s->num_nodes, M = s->num_tri_float4;
+        nodes.resize(N * 4);
+        std::memcpy(nodes.data(), s->bvh_nodes, N * 64);
+        recs.reserve((size_t)(s->num_tris + 1) * 4);
+        // record 0: a triangle nothing can hit, standing in for empty leaves
+        recs.push_back(make_float4(0, 0, 0, 0)); recs.push_back(make_float4(0, 0, 0, 0));
+        recs.push_back(make_float4(0, 0, 0, 0));
+        {
+            float4 meta = make_float4(0, 0, 0, 0);
+            uint32_t m[2] = {PT_PRIM_MISS, 3u};
+            std::memcpy(&meta, m, 8);
+            recs.push_back(meta);
+        }
+        const float *tf = s->bvh_tris;
+        auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        for (uint64_t i = 0; i < N; i++) {
+            int32_t ch[2];
+            std::memcpy(ch, &nodes[i * 4 + 3], 8);
+            for (int c = 0; c < 2; c++) {
+                if (ch[c] >= 0) {
+                    if ((uint64_t)ch[c] >= N) return fail(ctx, PT_ERR_ARG, "node %llu: child %d out of range",
+                                                          (unsigned long long)i, ch[c]);
+                    continue;
+                }
+                uint64_t a = (uint64_t)(uint32_t)~ch[c];
+                const uint64_t first = recs.size() / 4;
+                uint64_t count = 0;
+                // the reference's leaf loop stops at the first float4 whose x carries the bits 0x80000000
+                // (src/bvh.cuh:173-181), a real triangle with v00.x == -0.0f included
+                for (;; a += 3) {
+                    if (a >= M) return fail(ctx, PT_ERR_ARG, "node %llu: leaf run leaves the triangle buffer",
+                                            (unsigned long long)i);
+                    if (bits(tf[a * 4]) == 0x80000000u) break;
+                    if (a + 2 >= M) return fail(ctx, PT_ERR_ARG, "node %llu: truncated triangle", (unsigned long long)i);
+                    for (int r = 0; r < 3; r++)
+                        recs.push_back(make_float4(tf[(a + r) * 4], tf[(a + r) * 4 + 1], tf[(a + r) * 4 + 2],
+                                                   tf[(a + r) * 4 + 3]));
+                    float4 meta = make_float4(0, 0, 0, 0);
+                    uint32_t m[2] = {s->bvh_prim_ids ? s->bvh_prim_ids[a] : (uint32_t)a, 0u};
+                    std::memcpy(&meta, m, 8);
+                    recs.push_back(meta);
+                    count++;
+                }
+                int32_t ref;
+                if (count == 0) {
+                    ref = ~0;
+                } else {
+                    uint32_t m[2];
+                    std::memcpy(m, &recs[recs.size() - 1], 8);
+                    m[1] |= 1u;
+                    std::memcpy(&recs[recs.size() - 1], m, 8);
+                    ref = ~(int32_t)first;
+                }
+                ch[c] = ref;
+            }
+            std::memcpy(&nodes[i * 4 + 3], ch, 8);
+        }
+        // depth check: the traversal stack holds kMaxTreeDepth entries (the reference's STACK_SIZE, src/bvh.cuh:12)
+        {
+            std::vector<std::pair<uint32_t, uint32_t>> st;
+            st.push_back({0u, 1u});
+            uint64_t visited = 0;
+            uint32_t maxd = 0;
+            while (!st.empty()) {
+                auto [ni, dep] = st.back();
+                st.pop_back();
+                if (++visited > N) return fail(ctx, PT_ERR_ARG, "node graph is not a tree");
+                maxd = std::max(maxd, dep);
+                int32_t ch[2];
+                std::memcpy(ch, &nodes[(size_t)ni * 4 + 3], 8);
+                for (int c = 0; c < 2; c++)
+                    if (ch[c] >= 0) st.push_back({(uint32_t)ch[c], dep + 1});
+            }
+            if (maxd > (uint32_t)kMaxTreeDepth)
+                return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
+        }
+        int rc;
+        if ((rc = upload(ctx, nodes, &sc.nodes)) != PT_OK) return rc;
+        if ((rc = upload(ctx, recs, &sc.tris)) != PT_OK) return rc;
+        sc.has_bvh = 1;
+        sc.mesh_type = s->mesh_material_type;
+        sc.mesh_mat = make_float4(s->mesh_material[0], s->mesh_material[1], s->mesh_material[2], s->mesh_material[3]);
+    }
+
+    // ---- analytic primitives ------------------------------------------------------------------------------------
+    std::vector<DPlane> planes(s->num_planes);
+    for (uint64_t i = 0; i < s->num_planes; i++) {
+        const pt_plane &p = s->planes[i];
+        planes[i].pos = make_float4(p.position[0], p.position[1], p.position[2], 0);
+        planes[i].nrm = make_float4(p.normal[0], p.normal[1], p.normal[2], 0);
+        planes[i].mat = make_float4(p.material[0], p.material[1], p.material[2], p.material[3]);
+        planes[i].type = p.material_type;
+    }
+    std::vector<DSphere> spheres(s->num_spheres);
+    for (uint64_t i = 0; i < s->num_spheres; i++) {
+        const pt_sphere &p = s->spheres[i];
+        spheres[i].pos_r = make_float4(p.position[0], p.position[1], p.position[2], p.radius);
+        spheres[i].mat = make_float4(p.material[0], p.material[1], p.material[2], p.material[3]);
+        spheres[i].type = p.material_type;
+    }
+    if (s->num_planes >= (1u << 30) || s->num_spheres >= (1u << 30)) return fail(ctx, PT_ERR_ARG, "too many primitives");
+    int rc;
+    if ((rc = upload(ctx, planes, &sc.planes)) != PT_OK) return rc;
+    if ((rc = upload(ctx, spheres, &sc.spheres)) != PT_OK) return rc;
+    sc.num_planes = (uint32_t)s->num_planes;
+    sc.num_spheres = (uint32_t)s->num_spheres;
+
+    // ---- environment ----------------------------------------------------------------------------------------------
+    if (!s->env_texels || !s->env_marginal || !s->env_conditional || s->env_width == 0 || s->env_height == 0)
+        return fail(ctx, PT_ERR_ARG, "scene has no environment map (the reference requires one, src/scene.cu:219)");
+    if (s->env_width > 65535 || s->env_height > 65535) return fail(ctx, PT_ERR_ARG, "environment map larger than 65535");
+    {
+        const size_t W = s->env_width, H = s->env_height;
+        std::vector<float4> tex(W * H);
+        std::memcpy(tex.data(), s->env_texels, W * H * 16);
+        std::vector<uint16_t> marg(W), cond(W * H);
+        for (size_t i = 0; i < W; i++) {
+            if (s->env_marginal[i] >= W) return fail(ctx, PT_ERR_ARG, "env_marginal[%zu] out of range", i);
+            marg[i] = (uint16_t)s->env_marginal[i];
+        }
+        for (size_t i = 0; i < W * H; i++) {
+            if (s->env_conditional[i] >= H) return fail(ctx, PT_ERR_ARG, "env_conditional[%zu] out of range", i);
+            cond[i] = (uint16_t)s->env_conditional[i];
+        }
+        if ((rc = upload(ctx, tex, &sc.env)) != PT_OK) return rc;
+        if ((rc = upload(ctx, marg, &sc.marg)) != PT_OK) return rc;
+        if ((rc = upload(ctx, cond, &sc.cond)) != PT_OK) return rc;
+        sc.envW = s->env_width;
+        sc.envH = s->env_height;
+    }
+    sc.cam = s->camera;
+    ctx->sc = sc;
+    ctx->have_scene = true;
+    return PT_OK;
+}
+
+static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const Counters *cnt, uint32_t n_fixed,
+                         uint32_t n_upper, float4 *hit, float *t)
+{
+    int rc = ensure_gstk(ctx);
+    if (rc != PT_OK) return rc;
+    const int grid = extend_grid(ctx, n_upper);
+    unsigned long long *c3 = &ctx->cnt->trav[0];
+    if (ctx->count_traversal)
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, ro, rd, cnt, n_fixed, hit,
+                           t, ctx->gstk, c3);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, ro, rd, cnt, n_fixed, hit,
+                           t, ctx->gstk, c3);
+    HIPCHK(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4, void *d_hit4, void *d_t,
+                        pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_intersect_device: no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (n > 0xFFFFFFFFull) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: more than 2^32-1 rays in one call");
+    if (!d_org4 || !d_dir4 || !d_hit4 || !d_t) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: NULL buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->cnt, 0, sizeof(Counters), ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    int rc = launch_extend(ctx, (const float4 *)d_org4, (const float4 *)d_dir4, nullptr, (uint32_t)n, (uint32_t)n,
+                           (float4 *)d_hit4, (float *)d_t);
+    if (rc != PT_OK) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->rays = n; stats->iterations = 1; stats->extend_launches = 1;
+        stats->ms_total = ms; stats->ms_extend = ms;
+        stats->nodes = ctx->h_cnt->trav[0]; stats->tris = ctx->h_cnt->trav[1]; stats->leaves = ctx->h_cnt->trav[2];
+    }
+    return PT_OK;
+}
+
+int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, float *t_out, uint32_t *prim_out,
+                 float *normal_out)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_intersect: no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (!org || !dir || !t_out || !prim_out) return fail(ctx, PT_ERR_ARG, "pt_intersect: NULL buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t chunk = 1u << 20;
+    float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
+    float *d_t = nullptr;
+    const uint64_t cap = std::min(n, chunk);
+    std::vector<float4> ho(cap), hd(cap), hh(cap);
+    std::vector<float> ht(cap);
+    int rc = PT_OK;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_t); };
+#define ICHK(call)                                                                                              \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            cleanup();                                                                                          \
+            return fail(ctx, PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                       \
+        }                                                                                                       \
+    } while (0)
+    ICHK(hipMalloc(&d_o, cap * sizeof(float4)));
+    ICHK(hipMalloc(&d_d, cap * sizeof(float4)));
+    ICHK(hipMalloc(&d_h, cap * sizeof(float4)));
+    ICHK(hipMalloc(&d_t, cap * sizeof(float)));
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint64_t m = std::min(chunk, n - base);
+        for (uint64_t i = 0; i < m; i++) {
+            const float *po = org + 3 * (base + i), *pd = dir + 3 * (base + i);
+            ho[i] = make_float4(po[0], po[1], po[2], 0);
+            hd[i] = make_float4(pd[0], pd[1], pd[2], 0);
+        }
+        ICHK(hipMemcpyAsync(d_o, ho.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        ICHK(hipMemcpyAsync(d_d, hd.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        rc = launch_extend(ctx, d_o, d_d, nullptr, (uint32_t)m, (uint32_t)m, d_h, d_t);
+        if (rc != PT_OK) { cleanup(); return rc; }
+        ICHK(hipMemcpyAsync(hh.data(), d_h, m * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        ICHK(hipMemcpyAsync(ht.data(), d_t, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        ICHK(hipStreamSynchronize(ctx->stream));
+        for (uint64_t i = 0; i < m; i++) {
+            t_out[base + i] = ht[i];
+            uint32_t p;
+            std::memcpy(&p, &hh[i].w, 4);
+            prim_out[base + i] = p;
+            if (normal_out) {
+                normal_out[3 * (base + i)] = hh[i].x;
+                normal_out[3 * (base + i) + 1] = hh[i].y;
+                normal_out[3 * (base + i) + 2] = hh[i].z;
+            }
+        }
+    }
+#undef ICHK
+    cleanup();
+    return PT_OK;
+}
+
+int pt_primary_rays(pt_ctx *ctx, uint32_t W, uint32_t H, uint64_t sample, uint64_t seed, float *org_out, float *dir_out)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_primary_rays: no scene uploaded");
+    if (W < 2 || H < 2 || (uint64_t)W * H >= (1ull << 31) || !org_out || !dir_out || sample >= (1ull << 27))
+        return fail(ctx, PT_ERR_ARG, "pt_primary_rays: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)W * H;
+    float4 *d_o = nullptr, *d_d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_o, n * sizeof(float4)));
+    hipError_t e = hipMalloc(&d_d, n * sizeof(float4));
+    if (e != hipSuccess) { (void)hipFree(d_o); return fail(ctx, PT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_primary, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->sc, W, H,
+                       (uint32_t)sample, (uint32_t)seed, (uint32_t)(seed >> 32), d_o, d_d);
+    std::vector<float4> ho(n), hd(n);
+    e = hipMemcpyAsync(ho.data(), d_o, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_o);
+    (void)hipFree(d_d);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_primary_rays: %s", hipGetErrorString(e));
+    for (size_t i = 0; i < n; i++) {
+        org_out[3 * i] = ho[i].x; org_out[3 * i + 1] = ho[i].y; org_out[3 * i + 2] = ho[i].z;
+        dir_out[3 * i] = hd[i].x; dir_out[3 * i + 1] = hd[i].y; dir_out[3 * i + 2] = hd[i].z;
+    }
+    return PT_OK;
+}
+
+int pt_film_bind(pt_ctx *ctx, uint32_t W, uint32_t H, void *device_film)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (W < 2 || H < 2 || (uint64_t)W * H >= (1ull << 31)) return fail(ctx, PT_ERR_ARG, "film %ux%u not supported", W, H);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->film_owned) { (void)hipFree(ctx->film); }
+    ctx->film = nullptr;
+    ctx->film_owned = false;
+    ctx->W = W; ctx->H = H;
+    if (device_film) {
+        ctx->film = (float *)device_film;
+    } else {
+        HIPCHK(ctx, hipMalloc(&ctx->film, (size_t)W * H * 3 * sizeof(float)));
+        ctx->film_owned = true;
+        HIPCHK(ctx, hipMemsetAsync(ctx->film, 0, (size_t)W * H * 3 * sizeof(float), ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PT_OK;
+}
+
+int pt_film_clear(pt_ctx *ctx)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->film) return fail(ctx, PT_ERR_STATE, "pt_film_clear: no film bound");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->film, 0, (size_t)ctx->W * ctx->H * 3 * sizeof(float), ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_film_download(pt_ctx *ctx, float *rgb_out)
+{
+    if (!ctx || !rgb_out) return PT_ERR_ARG;
+    if (!ctx->film) return fail(ctx, PT_ERR_STATE, "pt_film_download: no film bound");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->film, (size_t)ctx->W * ctx->H * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint64_t seed, pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_render: no scene uploaded");
+    if (!ctx->film) return fail(ctx, PT_ERR_STATE, "pt_render: no film bound");
+    if (spp_total == 0 || spp_begin + spp_count > spp_total || spp_total >= (1ull << 27))
+        return fail(ctx, PT_ERR_ARG, "pt_render: sample range [%llu,+%llu) of %llu not supported",
+                    (unsigned long long)spp_begin, (unsigned long long)spp_count, (unsigned long long)spp_total);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_pool(ctx);
+    if (rc != PT_OK) return rc;
+    if ((rc = ensure_gstk(ctx)) != PT_OK) return rc;
+
+    const uint32_t P = ctx->pool, W = ctx->W, H = ctx->H;
+    const uint64_t total = (uint64_t)W * H * spp_count;
+    const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    hipStream_t st = ctx->stream;
+
+    Counters init{};
+    init.total_samples = total;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cnt, &init, sizeof init, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));   // init is a stack object
+    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
+
+    const int gs = stream_grid(ctx, P);
+    const uint64_t min_iters = (total + P - 1) / P;
+    uint64_t it = 0;
+    size_t ev_used = 0;
+    bool done = total == 0;
+    int cur = 0;       // buffer holding the extended rays
+    while (!done) {
+        PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
+        if (it > 0) {
+            hipLaunchKernelGGL(k_logic, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, ctx->cnt, ctx->queues, P, ctx->film,
+                               (float)spp_total, s0, s1);
+            hipLaunchKernelGGL(k_shade<0>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+            hipLaunchKernelGGL(k_shade<1>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+            hipLaunchKernelGGL(k_shade<2>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+            hipLaunchKernelGGL(k_shade<3>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+        }
+        hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)spp_begin,
+                           s0, s1);
+        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
+        if (ctx->time_extend) {
+            while (ctx->events.size() < ev_used + 2) {
+                hipEvent_t ev;
+                HIPCHK(ctx, hipEventCreate(&ev));
+                ctx->events.push_back(ev);
+            }
+            HIPCHK(ctx, hipEventRecord(ctx->events[ev_used], st));
+        }
+        rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hit, B.t);
+        if (rc != PT_OK) return rc;
+        if (ctx->time_extend) {
+            HIPCHK(ctx, hipEventRecord(ctx->events[ev_used + 1], st));
+            ev_used += 2;
+        }
+        cur ^= 1;
+        it++;
+        if (it >= min_iters) {
+            // poll the device counters two iterations behind the launch front
+            const int slot = (int)(it & 3);
+            HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[slot], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipEventRecord(ctx->poll_ev[slot], st));
+            if (it >= min_iters + 2) {
+                const int old = (int)((it - 2) & 3);
+                HIPCHK(ctx, hipEventSynchronize(ctx->poll_ev[old]));
+                const Counters &c = ctx->h_cnt[old];
+                if (c.n_in == 0 && c.next_sample >= c.total_samples) done = true;
+            }
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[0], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipGetLastError());
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        const Counters &c = ctx->h_cnt[0];
+        stats->rays = c.rays_total;
+        stats->paths = c.paths_total;
+        stats->iterations = c.iter;
+        stats->extend_launches = c.extend_nonempty;
+        stats->nodes = c.trav[0]; stats->tris = c.trav[1]; stats->leaves = c.trav[2];
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->ms_total = ms;
+        double ext = 0;
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float e = 0;
+            HIPCHK(ctx, hipEventElapsedTime(&e, ctx->events[i], ctx->events[i + 1]));
+            ext += e;
+        }
+        stats->ms_extend = ext;
+    }
+    return PT_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,165 @@
+/*
+ * pt_api.h -- C ABI of libpt_hip.so, the MI355X (gfx950) wavefront path-tracing hot path.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status returns (0 = ok, negative = error; the text is
+ * available from pt_last_error).  The caller owns every host buffer; the library owns every device buffer
+ * except a film the caller binds explicitly.  One pt_ctx per device; calls on one ctx must be serialised by
+ * the caller, different ctxs may be driven from different host threads.
+ *
+ * Each entry point names the reference interface (SuperMario210/cuda-path-tracer) it stands in for.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define PT_OK             0
+#define PT_ERR_ARG       (-1)   /* bad argument / scene the traversal cannot represent */
+#define PT_ERR_HIP       (-2)   /* a HIP runtime call failed */
+#define PT_ERR_STATE     (-3)   /* call order (no scene uploaded, no film bound, ...) */
+#define PT_ERR_NOMEM     (-4)
+
+/* material_type values: reference src/render.cuh:17-20 (IS_DIFFUSE .. IS_GLASS) */
+#define PT_DIFFUSE 0x4u
+#define PT_MIRROR  0x8u
+#define PT_GLOSSY  0x10u
+#define PT_GLASS   0x20u
+
+/* Primitive id of a closest hit.  Triangles report the id given in bvh_prim_ids (the OBJ face index). */
+#define PT_PRIM_MISS   0xFFFFFFFFu
+#define PT_PRIM_PLANE  0x80000000u   /* | index into planes  */
+#define PT_PRIM_SPHERE 0x40000000u   /* | index into spheres */
+
+typedef struct {                /* reference src/object.cuh:47-51 (class Plane) */
+    float position[3];
+    float normal[3];            /* unit length, as Plane's constructor leaves it (object.cuh:55) */
+    float material[4];          /* albedo rgb, w = IOR / glossyness (src/scene.cu:96-136) */
+    uint32_t material_type;
+} pt_plane;
+
+typedef struct {                /* reference src/object.cuh:13-18 (class Sphere) */
+    float position[3];
+    float radius;
+    float material[4];
+    uint32_t material_type;
+} pt_sphere;
+
+typedef struct {                /* reference src/camera.cuh:14-18 (class Camera, as uploaded at src/scene.cu:160-162) */
+    float origin[3];
+    float bottom_left[3];
+    float right[3];
+    float up[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float lens_radius;
+} pt_camera;
+
+/*
+ * Host-side description of a scene: exactly the buffers the reference's Scene constructor uploads
+ * (src/scene.cu:138-221), as host pointers.
+ *   bvh_nodes        GPUBVHNode[num_nodes], 64 B each (src/bvh.cu:36-41), as memcpy'd at src/bvh.cu:302
+ *   bvh_tris         float4[num_tri_float4] Woop rows with 0x80000000 leaf terminators and the zero float4 at
+ *                    index 0 (src/bvh.cu:224-226,240,275-277), as memcpy'd at src/bvh.cu:298
+ *   bvh_prim_ids     uint32[num_tri_float4] or NULL: id reported for the triangle whose first float4 sits at that
+ *                    index (NULL: the float4 index itself is reported)
+ *   env_texels       float4[env_height][env_width], row 0 = top of the .hdr, .w = solid-angle pdf
+ *                    (src/environment_map.cu:88-104,142-147)
+ *   env_marginal     size_t[env_width]; env_conditional size_t[env_width*env_height], index x*height+y
+ *                    (src/environment_map.cu:107-134)
+ * A scene without a mesh passes bvh_nodes = NULL, num_nodes = 0.
+ */
+typedef struct {
+    const float *bvh_nodes;
+    uint64_t num_nodes;
+    const float *bvh_tris;
+    uint64_t num_tri_float4;
+    const uint32_t *bvh_prim_ids;
+    uint64_t num_tris;
+    float mesh_material[4];
+    uint32_t mesh_material_type;
+    uint32_t reserved0;
+    const pt_plane *planes;
+    uint64_t num_planes;
+    const pt_sphere *spheres;
+    uint64_t num_spheres;
+    pt_camera camera;
+    uint32_t env_width;
+    uint32_t env_height;
+    const float *env_texels;
+    const uint64_t *env_marginal;
+    const uint64_t *env_conditional;
+} pt_scene_desc;
+
+typedef struct {
+    uint64_t rays;              /* closest-hit queries = active slots summed over extend launches */
+    uint64_t paths;             /* camera paths started */
+    uint64_t iterations;        /* wavefront iterations (one extend launch each) */
+    uint64_t extend_launches;   /* extend launches that had at least one ray */
+    double ms_total;            /* HIP-event time of the whole call on the ctx stream */
+    double ms_extend;           /* sum of HIP-event times of the extend launches */
+    uint64_t nodes;             /* traversal counters; filled only when PT_OPT_COUNT_TRAVERSAL is set */
+    uint64_t tris;
+    uint64_t leaves;
+} pt_stats;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Options for pt_set_option. */
+#define PT_OPT_POOL_SIZE        1   /* path slots in flight; the reference fixes 0x200000 (src/render.cuh:14) */
+#define PT_OPT_COUNT_TRAVERSAL  2   /* 1: extend counts nodes/triangles/leaves (slower; for roofline bookkeeping) */
+#define PT_OPT_TIME_EXTEND      3   /* 1 (default): bracket every extend launch with HIP events */
+
+/* No reference counterpart (the reference uses process-global device symbols, src/render.cu:47,91). */
+int  pt_ctx_create(int device_ordinal, pt_ctx **out);
+void pt_ctx_destroy(pt_ctx *ctx);
+const char *pt_last_error(const pt_ctx *ctx);          /* ctx may be NULL: error of a failed pt_ctx_create */
+int  pt_set_option(pt_ctx *ctx, int option, uint64_t value);
+
+/* Replaces the cudaMalloc/cudaMemcpy half of Scene::Scene, BVH::send_to_device and
+ * EnvironmentMap::send_to_device (reference src/scene.cu:160-214, src/bvh.cu:296-313,
+ * src/environment_map.cu:131-134,142-166). */
+int  pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene);
+
+/* Closest hit on a batch of rays given as host arrays of n*3 floats: the body of intersect_scene
+ * (reference src/render.cu:11-44) exposed for parity checks.  normal_out (n*3, unit length) may be NULL. */
+int  pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir,
+                  float *t_out, uint32_t *prim_out, float *normal_out);
+
+/* Same kernel on device-resident rays (float4 per origin/direction, xyz used; hit_out float4 = unit normal xyz +
+ * prim id bits, t_out float).  Used to time traversal alone.  stats may be NULL. */
+int  pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4,
+                         void *d_hit4, void *d_t, pt_stats *stats);
+
+/* Camera rays of one sample index exactly as the generate stage produces them (reference src/render.cu:93-127),
+ * written to host arrays of width*height*3 floats indexed by film pixel.  For parity checks. */
+int  pt_primary_rays(pt_ctx *ctx, uint32_t width, uint32_t height, uint64_t sample, uint64_t seed,
+                     float *org_out, float *dir_out);
+
+/* The film: float3[width*height], row 0 = top (reference Scene::image_data, src/scene.cu:216, src/render.cu:121).
+ * device_film = NULL lets the library allocate it; otherwise the caller's device buffer is accumulated into
+ * (e.g. a tensor that is reduced across GPUs afterwards). */
+int  pt_film_bind(pt_ctx *ctx, uint32_t width, uint32_t height, void *device_film);
+int  pt_film_clear(pt_ctx *ctx);
+int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcpy at reference src/main.cu:40 */
+
+/* Replaces render_scene (reference src/render.cuh:50, src/render.cu:244-280): accumulates samples
+ * [spp_begin, spp_begin+spp_count) of every pixel, each weighted 1/spp_total, into the bound film and returns
+ * when the device is done.  Splitting [0, spp_total) over several calls, contexts or GPUs and summing the films
+ * gives the same image as one call (up to float addition order). */
+int  pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint64_t seed,
+               pt_stats *stats);
+
+/* Stream the ctx launches on (a hipStream_t), for callers that want to order their own work after it. */
+void *pt_stream(pt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

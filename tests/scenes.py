@@ -1,0 +1,300 @@
+"""Scenes shared by the tests, the smoke check and the benchmark.
+
+Large generated assets (environment maps, the dragon stand-in) are written once to a cache directory outside the
+repository ($PT_ASSET_DIR, default /tmp/pt_assets).  The .scene texts below carry the reference's own camera,
+material and primitive values (reference scene/*.scene); only the asset paths differ.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def asset_dir():
+    d = os.environ.get("PT_ASSET_DIR", "/tmp/pt_assets")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def ensure_asset(pkg, kind):
+    path = os.path.join(asset_dir(), kind)
+    if not os.path.exists(path):
+        tmp = path + ".tmp%d" % os.getpid()
+        pkg.asset_generate(kind, tmp)
+        os.replace(tmp, path)
+    return path
+
+
+_MESHES = None
+
+
+def golden_mesh(name):
+    """(ntris, 3, 3) float32 triangles of one of the reference's shipped meshes, from tests/golden/meshes.npz."""
+    global _MESHES
+    if _MESHES is None:
+        _MESHES = np.load(os.path.join(GOLDEN, "meshes.npz"))
+    v = _MESHES[name + "_v"]
+    f = _MESHES[name + "_f"]
+    return np.ascontiguousarray(v[f], dtype=np.float32)
+
+
+def write_obj(path, tris):
+    """Writes triangles as an OBJ with the exact float values (%.9g round-trips float32)."""
+    with open(path, "w") as fh:
+        flat = tris.reshape(-1, 3)
+        for p in flat:
+            fh.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for i in range(tris.shape[0]):
+            fh.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+
+
+def ensure_mesh_obj(name):
+    path = os.path.join(asset_dir(), name + ".obj")
+    if not os.path.exists(path):
+        tmp = path + ".tmp%d" % os.getpid()
+        write_obj(tmp, golden_mesh(name))
+        os.replace(tmp, path)
+    return path
+
+
+SCENE_TEXT = {
+    # reference scene/balls.scene
+    "balls": """CAMERA
+position 0 1 5
+look_at 0 0.5 0
+fov 35
+aperture 0.1
+focus_dist 4.75
+
+ENVIRONMENT
+file_name {studio}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.325 0.3 0.35
+position 0 0 0
+normal 0 1 0
+
+SPHERE
+material_type GLASS
+albedo 1 1 1
+refraction_index 1.5
+position -2.025 0.5 0
+radius 0.5
+
+SPHERE
+material_type LAMBERTIAN
+albedo 0.7 0.7 0.7
+position -0.675 0.5 0
+radius 0.5
+
+SPHERE
+material_type MIRROR
+albedo 0.5 0.5 0.5
+position 0.675 0.5 0
+radius 0.5
+
+SPHERE
+material_type GLOSSY
+albedo 0.15 0.25 0.4
+specular 1 1 1
+glossyness 0.05
+position 2.025 0.5 0
+radius 0.5
+""",
+    # reference scene/bunny.scene
+    "bunny": """CAMERA
+position 1 1 4
+look_at -1 0.5 0
+fov 35
+aperture 0.1
+focus_dist 4
+
+ENVIRONMENT
+file_name {sunset}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.08 0.08 0.12
+position 0 0 0
+normal 0 1 0
+
+SPHERE
+material_type MIRROR
+albedo 0.5 0.5 0.5
+position -3 1.5 -0.5
+radius 1.5
+
+OBJ
+material_type LAMBERTIAN
+albedo 0.6 0.3 0.1
+file_name {bunny}
+""",
+    # reference scene/dragon.scene (the mesh is the procedural stand-in)
+    "dragon": """CAMERA
+position -1.1 0.2 -0.8
+look_at 0 0.0 0
+fov 38
+aperture 0.01
+focus_dist 1.15
+
+ENVIRONMENT
+file_name {forest}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.65 0.1 0.1
+position 0 -0.283 0
+normal 0 1 0
+
+OBJ
+material_type GLOSSY
+albedo 0.65 0.65 0.65
+specular 1 1 1
+glossyness 0.05
+file_name {dragon}
+""",
+}
+
+_SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"]}
+
+
+def scene_file(pkg, name):
+    """Writes <asset_dir>/<name>.scene (generating what it references) and returns its path."""
+    paths = {}
+    for kind in _SCENE_ASSETS[name]:
+        paths[kind.split(".")[0]] = ensure_asset(pkg, kind)
+    if name == "bunny":
+        paths["bunny"] = ensure_mesh_obj("bunny")
+    path = os.path.join(asset_dir(), name + ".scene")
+    text = SCENE_TEXT[name].format(**paths)
+    if not os.path.exists(path) or open(path).read() != text:
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as fh:
+            fh.write(text)
+        os.replace(tmp, path)
+    return path
+
+
+def small_env(pkg, width=64, height=32):
+    """A small closed-form lat-long map: dim gradient, one bright patch, one dark band (zero-luminance texels)."""
+    j, i = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    u = (i + 0.5) / width
+    v = (j + 0.5) / height
+    tex = np.zeros((height, width, 4), dtype=np.float32)
+    tex[..., 0] = 0.3 + 0.5 * v
+    tex[..., 1] = 0.4 + 0.2 * u
+    tex[..., 2] = 0.8 - 0.5 * v
+    patch = (np.abs(u - 0.3) < 0.06) & (np.abs(v - 0.3) < 0.08)
+    tex[patch, :3] = np.array([40.0, 35.0, 25.0], dtype=np.float32)
+    tex[(v > 0.9), :3] = 0.0
+    tex[..., 3] = 1.0
+    marg, cond = pkg.env_build(tex)
+    return tex, marg, cond
+
+
+def knot_mesh(pkg):
+    return pkg.obj_load(ensure_asset(pkg, "knot_small.obj"))
+
+
+def knot_scene(pkg, width, height, mesh_type=None, with_spheres=True):
+    """9,216-triangle knot (glossy) on a plane with glass, mirror and diffuse spheres around it; small environment."""
+    tris = knot_mesh(pkg)
+    bvh = pkg.bvh_build(tris)
+    cam = pkg.camera_make((-1.1, 0.35, -0.9), (0, -0.05, 0), 40.0, width / height, 0.02, 1.3)
+    tex, marg, cond = small_env(pkg)
+    planes = [pkg.make_plane((0, -0.283, 0), (0, 1, 0), (0.65, 0.1, 0.1, 0.0), pkg.DIFFUSE)]
+    spheres = []
+    if with_spheres:
+        spheres = [
+            pkg.make_sphere((0.1, -0.133, -0.62), 0.15, (1.0, 1.0, 1.0, 1.5), pkg.GLASS),
+            pkg.make_sphere((-0.55, -0.163, 0.1), 0.12, (0.5, 0.5, 0.5, 0.0), pkg.MIRROR),
+            pkg.make_sphere((0.55, -0.183, -0.25), 0.10, (0.7, 0.7, 0.2, 0.0), pkg.DIFFUSE),
+        ]
+    return pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
+                           mesh_material=(0.65, 0.65, 0.65, 0.05),
+                           mesh_material_type=pkg.GLOSSY if mesh_type is None else mesh_type)
+
+
+def mesh_scene(pkg, tris, width, height, cam_pos, look_at, fov=35.0, aperture=0.0, focus=4.0,
+               mesh_type=None, planes=None, spheres=None):
+    bvh = pkg.bvh_build(tris)
+    cam = pkg.camera_make(cam_pos, look_at, fov, width / height, aperture, focus)
+    tex, marg, cond = small_env(pkg)
+    return pkg.ManualScene(cam, tex, marg, cond, planes=planes or [], spheres=spheres or [], bvh=bvh,
+                           mesh_material=(0.6, 0.3, 0.1, 0.0),
+                           mesh_material_type=pkg.DIFFUSE if mesh_type is None else mesh_type)
+
+
+def spheres_scene(pkg, width, height):
+    """The reference's balls scene (one plane, four spheres, all four materials) over the small environment."""
+    cam = pkg.camera_make((0, 1, 5), (0, 0.5, 0), 35.0, width / height, 0.1, 4.75)
+    tex, marg, cond = small_env(pkg)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (0.325, 0.3, 0.35, 0.0), pkg.DIFFUSE)]
+    spheres = [
+        pkg.make_sphere((-2.025, 0.5, 0), 0.5, (1, 1, 1, 1.5), pkg.GLASS),
+        pkg.make_sphere((-0.675, 0.5, 0), 0.5, (0.7, 0.7, 0.7, 0.0), pkg.DIFFUSE),
+        pkg.make_sphere((0.675, 0.5, 0), 0.5, (0.5, 0.5, 0.5, 0.0), pkg.MIRROR),
+        pkg.make_sphere((2.025, 0.5, 0), 0.5, (0.15, 0.25, 0.4, 0.05), pkg.GLOSSY),
+    ]
+    return pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres)
+
+
+def as_oracle_desc(scene):
+    """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
+    import oracle_lib
+
+    desc = scene.desc if hasattr(scene, "desc") else scene
+    return C.cast(C.pointer(desc), C.POINTER(oracle_lib.SceneDesc)).contents
+
+
+def secondary_rays(org, dir_, t, nrm, seed):
+    """One bounce ray per hit: origin at the hit point, direction from a seeded cosine-ish lobe around the normal."""
+    rng = np.random.default_rng(seed)
+    hit = t < 3.0e38
+    o = (org[hit] + dir_[hit] * t[hit, None]).astype(np.float32)
+    r = rng.normal(size=o.shape).astype(np.float32)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    d = (nrm[hit] + r).astype(np.float32)
+    ln = np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where(ln > 1e-3, d / np.maximum(ln, 1e-12), nrm[hit]).astype(np.float32)
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
+
+
+def parity_cases(pkg, W=48, H=32):
+    """name -> scene for the fixed ray-batch fixtures (tests/golden/rays_<name>.npz)."""
+    return {
+        "knot": knot_scene(pkg, W, H),
+        "balls": spheres_scene(pkg, W, H),
+        "bunny_lowpoly": mesh_scene(pkg, golden_mesh("bunny_lowpoly"), W, H, (1, 1.5, 4), (0, 1.0, 0),
+                                    planes=[pkg.make_plane((0, 0, 0), (0, 1, 0), (0.3, 0.3, 0.3, 0), pkg.DIFFUSE)]),
+        "suzanne": mesh_scene(pkg, golden_mesh("suzanne"), W, H, (0, -0.05, 4), (0, -0.05, 0)),
+    }
+
+
+def ray_batch(scene, W, H, seed):
+    """Primary rays of the scene camera, one bounce ray per hit, and 256 axis-parallel / zero-component rays.
+
+    Built with the CPU oracle (test infrastructure); returns (org, dir) float32 arrays.
+    """
+    import oracle_lib as O
+
+    d = as_oracle_desc(scene)
+    org, dir_ = O.primary_rays(d, W, H, sample=0, seed=seed)
+    t, prim, nrm, _ = O.intersect(d, org, dir_, want_normals=True)
+    o2, d2 = secondary_rays(org, dir_, t, nrm, seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    k = 256
+    o3 = rng.uniform(-1.5, 1.5, size=(k, 3)).astype(np.float32)
+    d3 = np.zeros((k, 3), dtype=np.float32)
+    ax = rng.integers(0, 3, size=k)
+    d3[np.arange(k), ax] = rng.choice([-1.0, 1.0], size=k)
+    two = rng.random(k) < 0.5
+    ax2 = (ax + 1 + rng.integers(0, 2, size=k)) % 3
+    d3[np.arange(k)[two], ax2[two]] = rng.choice([-1.0, 1.0], size=two.sum())
+    d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+    o3[::7, 0] = 0.0        # origins on a coordinate plane: 0 * inf in the slab set-up
+    o3[::11, 1] = 0.0
+    return (np.concatenate([org, o2, o3]).astype(np.float32), np.concatenate([dir_, d2, d3]).astype(np.float32))

@@ -1,0 +1,361 @@
+"""CPU tests: the oracle against its pins and fixtures, the host-side scene assembly against the oracle, the C ABI
+surface of both shared libraries, and the multi-rank film reduction (gloo, two processes)."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import scenes as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = S.GOLDEN
+
+
+# ---- oracle pins -------------------------------------------------------------------------------------------------
+def test_philox_published_vectors():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    assert [int(x) for x in O.philox([0, 0, 0, 0], [0, 0])] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(x) for x in O.philox([0xffffffff] * 4, [0xffffffff] * 2)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6,
+                                                                              0x6d5451fd]
+    assert [int(x) for x in O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == [
+        0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+# Sizes of the buffers the reference's own builder produces for its shipped meshes (node buffer bytes, triangle
+# buffer bytes): 64 B per interior node; 16 B * (1 + 3*triangles + leaves).
+REFERENCE_BUFFER_SIZES = {
+    "bunny_lowpoly": (316, 11904, 18176),
+    "suzanne": (968, 37312, 55824),
+    "city": (14350, 491840, 811792),
+    "bunny": (28576, 1049280, 1634000),
+}
+
+
+@pytest.mark.parametrize("name", list(REFERENCE_BUFFER_SIZES))
+def test_oracle_bvh_structure(name):
+    ntris, node_bytes, tri_bytes = REFERENCE_BUFFER_SIZES[name]
+    tris = S.golden_mesh(name)
+    assert tris.shape[0] == ntris
+    b = O.bvh_build(tris)
+    assert b["nodes"].nbytes == node_bytes
+    assert b["num_tri_float4"] * 16 == tri_bytes
+    assert b["num_leaves"] == b["nodes"].shape[0] + 1
+    # every triangle appears exactly once, every leaf run is terminated
+    ids = b["prim_ids"]
+    assert sorted(ids[ids != O.PRIM_MISS].tolist()) == list(range(ntris))
+    term = b["tris"][: b["num_tri_float4"], 0].view(np.uint32) == 0x80000000
+    assert term.sum() == b["num_leaves"]
+    # children: node indices in range, leaf references inside the triangle buffer
+    ch = b["nodes"][:, 12:14].view(np.int32)
+    assert ((ch >= 0) & (ch < b["nodes"].shape[0]) | (ch < 0) & (~ch < b["num_tri_float4"])).all()
+    # the root's two boxes enclose the mesh
+    n0 = b["nodes"][0]
+    lo = np.minimum([n0[0], n0[2], n0[8]], [n0[4], n0[6], n0[10]])
+    hi = np.maximum([n0[1], n0[3], n0[9]], [n0[5], n0[7], n0[11]])
+    assert (lo <= tris.reshape(-1, 3).min(axis=0)).all() and (hi >= tris.reshape(-1, 3).max(axis=0)).all()
+
+
+@pytest.mark.parametrize("name", ["knot", "balls", "bunny_lowpoly", "suzanne"])
+def test_oracle_matches_golden_rays(pkg, name):
+    g = np.load(os.path.join(GOLDEN, "rays_%s.npz" % name))
+    scene = S.parity_cases(pkg)[name]
+    t, prim, _, _ = O.intersect(S.as_oracle_desc(scene), g["org"], g["dir"])
+    assert np.array_equal(prim, g["prim"])
+    assert np.array_equal(t, g["t"])
+
+
+def test_oracle_woop_hits_agree_with_moller_trumbore(pkg):
+    """Independent check of the traversal + Woop test: brute-force float64 Moller-Trumbore over every triangle."""
+    tris = S.golden_mesh("bunny_lowpoly")
+    scene = S.parity_cases(pkg)["bunny_lowpoly"]
+    d = S.as_oracle_desc(scene)
+    org, dir_ = O.primary_rays(d, 48, 32, sample=0, seed=11)
+    # only the mesh: compare against rays' nearest triangle
+    t, prim, _, _ = O.intersect(d, org, dir_)
+    v0, v1, v2 = (tris[:, k].astype(np.float64) for k in range(3))
+    e1, e2 = v1 - v0, v2 - v0
+    checked = 0
+    for i in range(org.shape[0]):
+        if prim[i] >= O.PRIM_SPHERE:
+            continue
+        o, dd = org[i].astype(np.float64), dir_[i].astype(np.float64)
+        p = np.cross(dd, e2)
+        det = (e1 * p).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            s = o - v0
+            u = (s * p).sum(1) * inv
+            q = np.cross(s, e1)
+            v = (q * dd).sum(1) * inv
+            tt = (e2 * q).sum(1) * inv
+        ok = (np.abs(det) > 1e-12) & (u >= -1e-9) & (v >= -1e-9) & (u + v <= 1 + 1e-9) & (tt > 1e-3)
+        assert ok.any()
+        best = np.where(ok, tt, np.inf).min()
+        assert abs(best - t[i]) <= 1e-4 * max(1.0, best)
+        checked += 1
+    assert checked > 100
+
+
+def test_oracle_render_energy_and_determinism(pkg):
+    scene = S.spheres_scene(pkg, 48, 32)
+    d = S.as_oracle_desc(scene)
+    a, sa = O.render(d, 48, 32, 0, 4, 4, seed=2, nthreads=1)
+    b, sb = O.render(d, 48, 32, 0, 4, 4, seed=2, nthreads=4)
+    assert np.array_equal(a, b) and sa.rays == sb.rays
+    assert np.isfinite(a).all() and a.min() >= 0 and a.mean() > 0.05
+    # sample partition: two halves sum to the whole
+    h0, _ = O.render(d, 48, 32, 0, 2, 4, seed=2)
+    h1, _ = O.render(d, 48, 32, 2, 2, 4, seed=2)
+    assert np.allclose(h0 + h1, a, rtol=1e-6, atol=1e-7)
+
+
+# ---- host-side scene assembly against the oracle ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bunny_lowpoly", "suzanne", "city", "bunny"])
+@pytest.mark.parametrize("threads", [1, 4])
+def test_host_bvh_equals_oracle(pkg, name, threads):
+    tris = S.golden_mesh(name)
+    a = pkg.bvh_build(tris, threads=threads)
+    b = O.bvh_build(tris)
+    for k in ("nodes", "tris", "prim_ids"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert a["max_depth"] == b["max_depth"] and a["num_leaves"] == b["num_leaves"]
+
+
+def test_host_bvh_parallel_build_equals_serial(pkg):
+    """A mesh large enough for the task-parallel path (subtrees of >= 32,768 triangles go to other threads)."""
+    tris = S.knot_mesh(pkg)
+    rng = np.random.default_rng(0)
+    big = np.concatenate([tris + rng.uniform(-3, 3, size=(1, 1, 3)).astype(np.float32) for _ in range(12)])
+    a = pkg.bvh_build(big, threads=1)
+    b = pkg.bvh_build(big, threads=8)
+    for k in ("nodes", "tris", "prim_ids"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+def test_host_bvh_rejects_tiny_meshes(pkg):
+    with pytest.raises(pkg.PtError):
+        pkg.bvh_build(np.zeros((2, 3, 3), np.float32))
+
+
+def test_host_bvh_degenerate_centroids(pkg):
+    """Identical triangles: the reference divides 0/0 here; both builders fall back to a median split."""
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    tris = np.repeat(tri, 9, axis=0)
+    a = pkg.bvh_build(tris)
+    b = O.bvh_build(tris)
+    assert np.array_equal(a["nodes"].view(np.uint32), b["nodes"].view(np.uint32))
+    assert np.array_equal(a["tris"].view(np.uint32), b["tris"].view(np.uint32))
+
+
+def test_host_env_equals_oracle(pkg):
+    tex, marg, cond = S.small_env(pkg, 64, 32)
+    tex2 = tex.copy()
+    tex2[..., 3] = 1.0
+    m2, c2 = O.env_build(tex2)
+    assert np.array_equal(tex.view(np.uint32), tex2.view(np.uint32))
+    assert np.array_equal(marg, m2) and np.array_equal(cond, c2)
+    # the bottom row's pdf is zero (sin(0) == 0), the pdf integrates to about one over the sphere
+    assert (tex[-1, :, 3] == 0).all()
+    H, W = tex.shape[:2]
+    theta = (np.arange(H) + 0.5) * np.pi / H
+    integral = (tex[..., 3] * np.sin(theta)[:, None]).sum() * (np.pi / H) * (2 * np.pi / W)
+    assert 0.8 < integral < 1.2
+
+
+def test_host_camera_equals_oracle(pkg):
+    for args in [((0, 1, 5), (0, 0.5, 0), 35.0, 16 / 9, 0.1, 4.75), ((-1.1, 0.2, -0.8), (0, 0, 0), 38.0, 1.5, 0.01, 1.15)]:
+        assert bytes(pkg.camera_make(*args)) == bytes(O.camera_make(*args))
+
+
+def test_hdr_roundtrip_and_rgbe_decode(pkg, tmp_path):
+    rng = np.random.default_rng(1)
+    img = (rng.random((16, 40, 3)) ** 4 * 100).astype(np.float32)
+    img[3, :, :] = 0.0                     # an all-zero scanline: long runs
+    img[5, 10:30, :] = 7.5                 # a run inside a scanline
+    path = str(tmp_path / "t.hdr")
+    pkg.hdr_write(path, img)
+    back = pkg.hdr_load(path)
+    assert back.shape == (16, 40, 4) and (back[..., 3] == 1).all()
+    # RGBE keeps 8 mantissa bits of the largest channel
+    mx = img.max(axis=2, keepdims=True)
+    assert np.all(np.abs(back[..., :3] - img) <= mx / 128 + 1e-30)
+    # decoding agrees with the oracle's restatement of stb_image's conversion
+    raw = open(path, "rb").read()
+    assert raw.startswith(b"#?RADIANCE\n")
+    rgbe = np.array([[128, 64, 32, 130], [0, 0, 0, 0], [255, 1, 2, 120], [7, 7, 7, 1]], np.uint8)
+    out = np.zeros((4, 4), np.float32)
+    O.lib().orc_rgbe_to_float(O.ptr(rgbe), 4, O.ptr(out))
+    assert out[0].tolist() == [2.0, 1.0, 0.5, 1.0] and out[1].tolist() == [0, 0, 0, 1]
+    # a flat (non run-length) file decodes too
+    flat = str(tmp_path / "flat.hdr")
+    with open(flat, "wb") as fh:
+        fh.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 8\n")
+        px = np.tile(np.array([[128, 64, 32, 130]], np.uint8), (16, 1))
+        fh.write(px.tobytes())
+    f = pkg.hdr_load(flat)
+    assert f.shape == (2, 8, 4) and np.allclose(f[..., :3], [2.0, 1.0, 0.5])
+
+
+def test_tonemap_and_png(pkg, tmp_path):
+    rng = np.random.default_rng(2)
+    film = (rng.random((9, 13, 3)) * 3).astype(np.float32)
+    a = pkg.tonemap16(film)
+    b = O.tonemap16(film)
+    assert np.array_equal(a, b)
+    path = str(tmp_path / "o.png")
+    pkg.png16_write(path, a)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + data) == crc
+        chunks[typ] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (w, h, depth, ctype) == (13, 9, 16, 2)
+    rows = zlib.decompress(chunks[b"IDAT"])
+    stride = 1 + 13 * 6
+    px = np.frombuffer(b"".join(rows[r * stride + 1:(r + 1) * stride] for r in range(9)), dtype=">u2").reshape(9, 13, 3)
+    assert np.array_equal(px.astype(np.uint16), a)
+
+
+def test_scene_file_loading(pkg, tmp_path):
+    """A .scene file in the reference's format: blocks, materials, and asset paths relative to the scene file."""
+    tris = S.golden_mesh("bunny_lowpoly")
+    S.write_obj(str(tmp_path / "m.obj"), tris)
+    env = np.ones((8, 16, 3), np.float32)
+    env[2, 3] = 50.0
+    pkg.hdr_write(str(tmp_path / "e.hdr"), env)
+    text = """CAMERA
+position 1 1 4
+look_at -1 0.5 0
+fov 35
+aperture 0.1
+focus_dist 4
+
+ENVIRONMENT
+file_name e.hdr
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.08 0.08 0.12
+position 0 0 0
+normal 0 2 0
+
+SPHERE
+material_type GLASS
+albedo 1 1 1
+refraction_index 1.5
+position -3 1.5 -0.5
+radius 1.5
+
+OBJ
+material_type GLOSSY
+albedo 0.6 0.3 0.1
+specular 1 1 1
+glossyness 0.05
+file_name m.obj
+"""
+    (tmp_path / "s.scene").write_text(text)
+    sc = pkg.HostScene(str(tmp_path / "s.scene"), 64, 48)
+    d = sc.desc
+    assert d.num_planes == 1 and d.num_spheres == 1 and d.num_tris == 316
+    assert d.mesh_material_type == pkg.GLOSSY and abs(d.mesh_material[3] - 0.05) < 1e-7
+    pl = C.cast(d.planes, C.POINTER(pkg.Plane))[0]
+    assert list(pl.normal) == [0.0, 1.0, 0.0]
+    sp = C.cast(d.spheres, C.POINTER(pkg.Sphere))[0]
+    assert sp.material_type == pkg.GLASS and sp.material[3] == 1.5 and sp.radius == 1.5
+    assert (d.env_width, d.env_height) == (16, 8)
+    assert bytes(d.camera) == bytes(O.camera_make((1, 1, 4), (-1, 0.5, 0), 35.0, 64 / 48, 0.1, 4.0))
+    # the mesh buffers are the ones the builder gives for the same triangles
+    b = O.bvh_build(tris)
+    nodes = np.ctypeslib.as_array(C.cast(d.bvh_nodes, C.POINTER(C.c_float)), shape=(d.num_nodes, 16))
+    assert np.array_equal(nodes.view(np.uint32), b["nodes"].view(np.uint32))
+    # the oracle can render it
+    film, st = O.render(S.as_oracle_desc(sc), 64, 48, 0, 1, 1)
+    assert st.paths == 64 * 48 and np.isfinite(film).all()
+    sc.close()
+    with pytest.raises(pkg.PtError):
+        pkg.HostScene(str(tmp_path / "missing.scene"), 64, 48)
+
+
+def test_obj_loader_superset(pkg, tmp_path):
+    (tmp_path / "a.obj").write_text("# comment\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\n\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4 -3 -2\n")
+    t = pkg.obj_load(str(tmp_path / "a.obj"))
+    assert t.shape == (3, 3, 3)
+    assert t[0].tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0]]
+    assert t[1].tolist() == [[0, 0, 0], [1, 1, 0], [0, 1, 0]]
+    assert t[2].tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0]]
+
+
+def test_generated_assets(pkg):
+    knot = S.knot_mesh(pkg)
+    assert knot.shape == (9216, 3, 3)
+    assert abs(float(knot[..., 1].min()) + 0.283) < 1e-6
+    b = pkg.bvh_build(knot)
+    assert b["max_depth"] <= 63
+
+
+# ---- C ABI surface -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("header,lib", [("pt_api.h", "libpt_hip.so"), ("pt_host.h", "libpt_host.so")])
+def test_c_abi_exports_every_declared_symbol(header, lib):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(pth?_[a-z0-9_]+)\s*\(", text))
+    assert len(names) >= 10
+    path = os.path.join(ROOT, "cuda-path-tracer_amd", lib)
+    assert os.path.exists(path), "%s is not built" % lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert names <= exported, "missing: %s" % sorted(names - exported)
+
+
+def test_hip_library_loads_and_reports_missing_gpu(pkg):
+    """Without a GPU the device library still loads; creating a context fails with a message instead of falling back."""
+    import torch
+
+    L = pkg.hip_lib()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert L.pt_ctx_create(0, C.byref(h)) != 0
+    assert b"HIP" in L.pt_last_error(None) or b"device" in L.pt_last_error(None)
+    with pytest.raises(pkg.PtError):
+        pkg.Context(0)
+
+
+# ---- multi-rank: samples-per-pixel partition + film reduction ---------------------------------------------------------
+def test_spp_partition(pkg):
+    for spp, ws in [(512, 8), (7, 3), (2, 4), (2048, 8)]:
+        parts = [pkg.spp_partition(spp, ws, r) for r in range(ws)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
+        for (b0, c0), (b1, _) in zip(parts, parts[1:]):
+            assert b0 + c0 == b1
+
+
+def test_two_rank_film_reduce_gloo(tmp_path):
+    """world_size 2 over gloo: each rank renders its share of the samples (CPU oracle standing in for the device),
+    the films are summed onto rank 0 with one reduce, and the result equals the single-rank film."""
+    script = os.path.join(ROOT, "tests", "dist_worker.py")
+    out = str(tmp_path / "film.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", env["MASTER_PORT"], script, out]
+    subprocess.check_call(cmd, env=env, cwd=ROOT, timeout=300)
+    got = np.load(out)
+    import __graft_entry__ as G
+
+    pkg = G.load_package()
+    scene = S.spheres_scene(pkg, 48, 32)
+    want, _ = O.render(S.as_oracle_desc(scene), 48, 32, 0, 6, 6, seed=4)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
