@@ -109,6 +109,13 @@ def hip_lib():
         path = os.path.join(PKG_DIR, "libpt_hip.so")
         if not os.path.exists(path):
             raise PtError("libpt_hip.so is not built: run `make -C %s`" % PKG_DIR)
+        try:
+            # PyTorch wheels bundle their own HIP/HSA runtime under the same soname.  Two runtimes in one process do
+            # not share the GPU (the second reports "no HIP GPUs"), so when torch is installed it is loaded first and
+            # this library binds to the runtime torch brought.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.pt_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.pt_ctx_destroy.argtypes = [C.c_void_p]

@@ -135,8 +135,15 @@ __device__ __forceinline__ void hit_sphere(const DSphere &sp, uint32_t idx, f3 o
     }
 }
 
-// reference src/bvh.cuh:75-88; the integer compares of src/bvh.cuh:18-27 become v_min/max(3)_i32.  nood = -ood with
-// NaNs kept positive so a NaN always compares above every number, as on the reference's hardware.
+// reference src/bvh.cuh:75-88; the integer compares of src/bvh.cuh:18-27 become v_min/max(3)_i32.
+// The reference's hardware turns every NaN into the positive pattern 0x7FFFFFFF, which as a signed integer is above
+// every number; gfx950 generates the negative pattern 0xFFC00000, which orders differently.  NaNs appear only for rays
+// with a zero (or denormal-small) direction component, so CANON = true (chosen per wave when any of its rays is such
+// a ray) rewrites NaNs to a positive pattern before they are compared; CANON = false is the same arithmetic without
+// that step.  nood = -(o/d), with NaNs already positive.
+__device__ __forceinline__ float pos_nan(float x) { return (x != x) ? fl(0x7FC00000) : x; }
+
+template <bool CANON>
 __device__ __forceinline__ bool hit_aabb(f3 inv, f3 nood, float x0, float x1, float y0, float y1, float z0, float z1,
                                          float t_max, float &t0)
 {
@@ -146,10 +153,21 @@ __device__ __forceinline__ bool hit_aabb(f3 inv, f3 nood, float x0, float x1, fl
     float hiy = __fmaf_rn(y1, inv.y, nood.y);
     float loz = __fmaf_rn(z0, inv.z, nood.z);
     float hiz = __fmaf_rn(z1, inv.z, nood.z);
+    if (CANON) {
+        lox = pos_nan(lox); hix = pos_nan(hix); loy = pos_nan(loy); hiy = pos_nan(hiy); loz = pos_nan(loz); hiz = pos_nan(hiz);
+    }
     int b = max(max(fi(fminf(lox, hix)), fi(fminf(loy, hiy))), max(min(fi(loz), fi(hiz)), fi(kEps)));
     int e = min(min(fi(fmaxf(lox, hix)), fi(fmaxf(loy, hiy))), min(max(fi(loz), fi(hiz)), fi(t_max)));
     t0 = fl(b);
     return fl(e) >= t0;
+}
+
+// True for rays whose slab arithmetic can produce a NaN or an infinity: a direction component that is zero or so small
+// that 1/d times a coordinate below 1e18 could overflow.
+__device__ __forceinline__ bool slab_degenerate(f3 d)
+{
+    const float tiny = 1e-18f;
+    return !(fabsf(d.x) >= tiny && fabsf(d.y) >= tiny && fabsf(d.z) >= tiny);
 }
 
 // reference src/bvh.cuh:93-120

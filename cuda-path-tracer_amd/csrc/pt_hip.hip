@@ -59,7 +59,7 @@ __device__ __forceinline__ int mat_slot(uint32_t type)
 // --------------------------------------------------------------------------------------------------------------
 // extend: closest hit (reference src/render.cu:11-44, src/bvh.cuh:130-189)
 // --------------------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool CANON>
 __device__ __forceinline__ void traverse(const DScene &sc, f3 o, f3 d, Hit &h, int (*stk)[kBlock], int *gstk,
                                          uint32_t gstride, uint32_t gtid, unsigned long long *cnt3)
 {
@@ -90,8 +90,8 @@ __device__ __forceinline__ void traverse(const DScene &sc, f3 o, f3 d, Hit &h, i
             const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
             if (COUNT) c_nodes++;
             float t0l, t0r;
-            bool hl = hit_aabb(inv, nood, lxy.x, lxy.y, lxy.z, lxy.w, z.x, z.y, h.t, t0l);
-            bool hr = hit_aabb(inv, nood, rxy.x, rxy.y, rxy.z, rxy.w, z.z, z.w, h.t, t0r);
+            bool hl = hit_aabb<CANON>(inv, nood, lxy.x, lxy.y, lxy.z, lxy.w, z.x, z.y, h.t, t0l);
+            bool hr = hit_aabb<CANON>(inv, nood, rxy.x, rxy.y, rxy.z, rxy.w, z.z, z.w, h.t, t0r);
             if (hl || hr) {
                 int far_child = ch.y;
                 node = hl ? ch.x : ch.y;
@@ -141,7 +141,11 @@ __global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4 *__re
         h.t = kFltMax; h.prim = PT_PRIM_MISS; h.n = mk3(0, 0, 0);
         for (uint32_t k = 0; k < sc.num_planes; k++) hit_plane(sc.planes[k], k, o, d, h);
         for (uint32_t k = 0; k < sc.num_spheres; k++) hit_sphere(sc.spheres[k], k, o, d, h);
-        if (sc.has_bvh) traverse<COUNT>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
+        if (sc.has_bvh) {
+            // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
+            if (__any(slab_degenerate(d))) traverse<COUNT, true>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
+            else traverse<COUNT, false>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
+        }
         f3 nn = h.prim == PT_PRIM_MISS ? mk3(0, 0, 0) : normalize3(h.n);     // reference src/render.cu:41
         hit_out[i] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(h.prim));
         t_out[i] = h.t;

@@ -77,18 +77,27 @@ def test_empty_and_single_ray(pkg, ctx):
 
 
 def film_metrics(a, b):
-    """relMSE = mean((a-b)^2 / (b^2 + 1e-2)) over channels, and the share of pixels differing by more than 1e-4."""
+    """relMSE = mean((a-b)^2 / (b^2 + 1e-2)) over channels, and the share of pixels whose largest channel difference
+    exceeds 1e-3 of the pixel's magnitude."""
     d = a.astype(np.float64) - b.astype(np.float64)
     rel_mse = float(np.mean(d * d / (b.astype(np.float64) ** 2 + 1e-2)))
-    differing = float((np.abs(d).max(axis=2) > 1e-4 * (1 + np.abs(b).max(axis=2))).mean())
+    differing = float((np.abs(d).max(axis=2) > 1e-3 * (1e-3 + np.abs(b).max(axis=2))).mean())
     return rel_mse, differing
+
+
+# Film tolerance against the oracle at equal spp and equal seed.  Both sides draw the same random numbers, so a pixel
+# differs only through ulp-level differences between the device's and libm's sin/cos/atan2/acos/pow and the order of
+# the float atomics (about 1e-5 relative), except where such a difference flips a discrete decision of one path (a
+# silhouette hit, a Russian-roulette or lobe choice) and that path's whole contribution changes.  Measured on MI355X:
+# 0.05 % of the pixels at 1 spp.  Stated bar: at most 1 % of the pixels differ by more than 1e-3 relative, and the
+# relMSE against the oracle is below 5 % of the Monte-Carlo noise floor (relMSE between two oracle renders that differ
+# only in seed).
+MAX_DIFFERING_PIXELS = 0.01
+MAX_RELMSE_OVER_NOISE = 0.05
 
 
 @pytest.mark.parametrize("name", ["knot", "balls"])
 def test_render_matches_oracle(pkg, ctx, name):
-    """Same seed -> same random decisions on both sides.  Only libm-vs-device ulp differences in sin/cos/atan2/acos/pow
-    and the float atomic order remain, so the films must agree far below Monte-Carlo noise:
-    relMSE <= 1e-4 and at most 2 % of pixels differing at all (a flipped discrete decision changes a whole path)."""
     W, H, spp = 96, 64, 8
     scene = S.knot_scene(pkg, W, H) if name == "knot" else S.spheres_scene(pkg, W, H)
     ctx.upload(scene)
@@ -99,12 +108,32 @@ def test_render_matches_oracle(pkg, ctx, name):
     assert st.paths == W * H * spp == ost.paths
     assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
     rel_mse, differing = film_metrics(film, ofilm)
-    assert rel_mse <= 1e-4, "relMSE %g" % rel_mse
-    assert differing <= 0.02, "%.3f of the pixels differ" % differing
-    # noise floor for scale: two oracle renders with different seeds
     ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
     floor, _ = film_metrics(ofilm2, ofilm)
-    assert rel_mse < 0.01 * floor
+    assert differing <= MAX_DIFFERING_PIXELS, "%.4f of the pixels differ" % differing
+    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
+    # tone-mapped 16-bit images: RMSE below a quarter of the seed-to-seed RMSE at this sample count
+    tm = lambda f: pkg.tonemap16(f).astype(np.float64) / 65535
+    rmse = np.sqrt(np.mean((tm(film) - tm(ofilm)) ** 2))
+    rmse_noise = np.sqrt(np.mean((tm(ofilm2) - tm(ofilm)) ** 2))
+    assert rmse <= 0.25 * rmse_noise, "tone-mapped RMSE %g vs noise %g" % (rmse, rmse_noise)
+
+
+def test_converged_render_matches_oracle(pkg, ctx):
+    """A small frame taken close to convergence (1024 spp): absolute bar on the tone-mapped image,
+    RMSE <= 0.01 of full scale, and relMSE of the linear film <= 1e-3."""
+    W, H, spp = 64, 48, 1024
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=2)
+    film = ctx.film_download()
+    ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2)
+    rel_mse, _ = film_metrics(film, ofilm)
+    tm = lambda f: pkg.tonemap16(f).astype(np.float64) / 65535
+    rmse = np.sqrt(np.mean((tm(film) - tm(ofilm)) ** 2))
+    assert rmse <= 0.01, "tone-mapped RMSE %g" % rmse
+    assert rel_mse <= 1e-3, "relMSE %g" % rel_mse
 
 
 def test_render_is_partition_invariant(pkg, ctx):
@@ -216,4 +245,6 @@ def test_full_size_frame_properties(pkg, ctx):
     # and a strip of it against the oracle: the same pixels rendered by the CPU
     ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=1, nthreads=16)
     rel_mse, differing = film_metrics(full, ofilm)
-    assert rel_mse <= 1e-4 and differing <= 0.02
+    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2, nthreads=16)
+    floor, _ = film_metrics(ofilm2, ofilm)
+    assert differing <= MAX_DIFFERING_PIXELS and rel_mse <= MAX_RELMSE_OVER_NOISE * floor, (differing, rel_mse, floor)
