@@ -1,8 +1,8 @@
 // libpt_hip.so: wavefront path tracing on MI355X (gfx950) behind the C ABI of include/pt_api.h.
 //
 // One wavefront iteration advances every live path by one segment:
-//   logic    (terminate on miss / depth limit -> film, Russian roulette, sort survivors into 4 material queues
-//             with one wave-aggregated atomic per material and wave)
+//   logic    (terminate on miss / depth limit, Russian roulette, sort survivors into 4 material queues with one
+//             wave-aggregated atomic per material and wave)
 //   shade x4 (one kernel per material reads its queue and writes the continued ray, compacted, into the other
 //             path buffer)
 //   generate (fills the rest of that buffer with new camera paths)
@@ -10,6 +10,13 @@
 //   extend   (closest hit for every ray of the new buffer)
 // Path state ping-pongs between two SoA buffers, so every state access except the queue gather is a coalesced
 // 16 B-per-lane stream.  All counters live on the device; the host only polls them (lagging) to learn when to stop.
+//
+// Film accumulation uses no atomics.  Every camera path ends exactly once (miss, depth limit or Russian roulette) and
+// at that point stores its contribution (zero when roulette killed it) into its own float4 of a "sample slab"
+// indexed [sample][pixel]; scattered float atomics run an order of magnitude below plain stores on this chip, and HBM
+// is large enough to hold a slab of hundreds of samples per pixel.  When a slab's samples have all ended, one
+// streaming kernel sums them per pixel in sample order and adds the sum to the film, so the film is reproducible bit
+// for bit from run to run.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,7 +34,7 @@ using namespace ptd;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kLdsDepth = 24;          // traversal stack entries kept in LDS per lane; deeper entries go to global
+constexpr int kLdsDepth = 16;          // traversal stack entries kept in LDS per lane; deeper entries go to global
 constexpr uint32_t kDefaultPool = 1u << 22;
 
 struct PathBuf {
@@ -168,59 +175,79 @@ __device__ __forceinline__ float4 material_of(const DScene &sc, uint32_t prim)
     return sc.mesh_mat;
 }
 
+constexpr int kLogicBatches = 8;     // 64-ray batches a wave settles before it touches the queue counters
+
 __global__ __launch_bounds__(kBlock) void k_logic(DScene sc, PathBuf A, Counters *cnt, uint32_t *__restrict__ queues,
-                                                  uint32_t P, float *__restrict__ film, float spp_total,
-                                                  uint32_t seed0, uint32_t seed1)
+                                                  uint32_t P, float4 *__restrict__ slab, uint32_t slab_first_sample,
+                                                  uint32_t npix, float spp_total, uint32_t seed0, uint32_t seed1)
 {
     const uint32_t n = cnt->n_in;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
-        const uint32_t i = base + lane;
-        int slot = -1;
-        if (i < n) {
-            const float t = A.t[i];
-            const float4 d4 = A.d[i];
-            float4 th = A.thr[i];
-            const uint32_t pixel = __float_as_uint(d4.w);
-            const uint32_t sk = __float_as_uint(th.w);
-            const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-            if (t == kFltMax || 2 * k >= kMaxDepth) {
-                // miss or depth limit: throughput * env(direction) / spp goes to the film (src/render.cu:62-72)
-                const float4 e = env_lookup(sc, xyz(d4));
-                float *px = film + 3 * (size_t)pixel;
-                unsafeAtomicAdd(px + 0, th.x * e.x / spp_total);
-                unsafeAtomicAdd(px + 1, th.y * e.y / spp_total);
-                unsafeAtomicAdd(px + 2, th.z * e.z / spp_total);
-            } else {
-                bool alive = true;
-                if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
-                    Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
-                    const float p = fmaxf(th.x, fmaxf(th.y, th.z));
-                    if (rng.next() > p) {
-                        alive = false;
-                    } else {
-                        const float ip = 1 / p;
-                        th.x *= ip; th.y *= ip; th.z *= ip;
-                        A.thr[i] = th;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
+    constexpr uint32_t kSpan = kLogicBatches * 64;
+    // Each wave owns spans of kLogicBatches * 64 consecutive rays.  It decides every ray of a span first, then claims
+    // queue space with ONE atomic per material for the whole span: all waves add to the same four counters, and
+    // same-address atomics are what this kernel would otherwise wait for.
+    for (uint32_t span = wave; (uint64_t)span * kSpan < n; span += nwaves) {
+        int slots[kLogicBatches];
+        uint32_t total[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < kLogicBatches; b++) {
+            const uint32_t i = span * kSpan + b * 64 + lane;
+            int slot = -1;
+            if (i < n) {
+                const float t = A.t[i];
+                const float4 d4 = A.d[i];
+                float4 th = A.thr[i];
+                const uint32_t pixel = __float_as_uint(d4.w);
+                const uint32_t sk = __float_as_uint(th.w);
+                const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+                if (t == kFltMax || 2 * k >= kMaxDepth) {
+                    // miss or depth limit: the path contributes throughput * env(direction) / spp (src/render.cu:62-72)
+                    const float4 e = env_lookup(sc, xyz(d4));
+                    slab[(size_t)(sample - slab_first_sample) * npix + pixel] =
+                        make_float4(th.x * e.x / spp_total, th.y * e.y / spp_total, th.z * e.z / spp_total, 0.0f);
+                } else {
+                    bool alive = true;
+                    if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+                        Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+                        const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+                        if (rng.next() > p) {
+                            alive = false;
+                            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        } else {
+                            const float ip = 1 / p;
+                            th.x *= ip; th.y *= ip; th.z *= ip;
+                            A.thr[i] = th;
+                        }
                     }
+                    if (alive) slot = mat_slot(material_type_of(sc, __float_as_uint(A.hit[i].w)));
                 }
-                if (alive) slot = mat_slot(material_type_of(sc, __float_as_uint(A.hit[i].w)));
             }
+            slots[b] = slot;
+#pragma unroll
+            for (int m = 0; m < 4; m++) total[m] += (uint32_t)__popcll(__ballot(slot == m));
         }
-        // wave-aggregated queue append: one atomic per material and wave
+        // wave-aggregated queue append: one atomic per material, wave and span
+        uint32_t base[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            const bool mine = slot == m;
-            const unsigned long long mask = __ballot(mine);
-            if (mask) {
+            uint32_t pos = 0;
+            if (total[m] != 0 && lane == 0) pos = atomicAdd(&cnt->q_count[m], total[m]);
+            base[m] = __shfl(pos, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < kLogicBatches; b++) {
+            const uint32_t i = span * kSpan + b * 64 + lane;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const bool mine = slots[b] == m;
+                const unsigned long long mask = __ballot(mine);
                 const uint32_t prefix =
                     __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                const int leader = __ffsll((long long)mask) - 1;
-                uint32_t pos = 0;
-                if ((int)lane == leader) pos = atomicAdd(&cnt->q_count[m], (uint32_t)__popcll(mask));
-                pos = __shfl(pos, leader);
-                if (mine) queues[(size_t)m * P + pos + prefix] = i;
+                if (mine) queues[(size_t)m * P + base[m] + prefix] = i;
+                base[m] += (uint32_t)__popcll(mask);
             }
         }
     }
@@ -340,6 +367,22 @@ __global__ void k_advance(Counters *cnt, uint32_t P)
     cnt->q_count[0] = cnt->q_count[1] = cnt->q_count[2] = cnt->q_count[3] = 0;
 }
 
+// Sums a pixel's slab entries in sample order and adds the sum to the film (float3 per pixel, row 0 = top).
+__global__ __launch_bounds__(kBlock) void k_film_reduce(const float4 *__restrict__ slab, uint32_t nsamples, uint32_t npix,
+                                                        float *__restrict__ film)
+{
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npix; p += gridDim.x * kBlock) {
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        const float4 *src = slab + p;
+        for (uint32_t s = 0; s < nsamples; s++) {
+            const float4 v = src[(size_t)s * npix];
+            r += v.x; g += v.y; b += v.z;
+        }
+        float *px = film + 3 * (size_t)p;
+        px[0] += r; px[1] += g; px[2] += b;
+    }
+}
+
 // camera rays of one sample index in film-pixel order (parity check of the generate stage)
 __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, uint32_t sample, uint32_t seed0,
                                                     uint32_t seed1, float4 *__restrict__ ro, float4 *__restrict__ rd)
@@ -383,6 +426,11 @@ struct pt_ctx {
     bool film_owned = false;
     uint32_t W = 0, H = 0;
 
+    // sample slab: float4 [samples][pixels]
+    float4 *slab = nullptr;
+    size_t slab_bytes = 0;
+    uint64_t slab_budget = 32ull << 30;
+
     // wavefront state
     uint32_t pool_alloc = 0;
     PathBuf buf[2]{};
@@ -419,8 +467,8 @@ static int fail(pt_ctx *ctx, int code, const char *fmt, ...)
 
 static int extend_grid(const pt_ctx *ctx, uint64_t n)
 {
-    // LDS (24 KB per block) admits 6 blocks of 256 threads per CU
-    const uint64_t cap = (uint64_t)ctx->num_cus * 6;
+    // 16 KB of LDS per block and 40 VGPRs admit 8 blocks of 256 threads (32 waves) per CU
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
     const uint64_t need = (n + kBlock - 1) / kBlock;
     return (int)std::max<uint64_t>(1, std::min(cap, need));
 }
@@ -433,7 +481,7 @@ static int stream_grid(const pt_ctx *ctx, uint64_t n)
 
 static int ensure_gstk(pt_ctx *ctx)
 {
-    const size_t threads = (size_t)ctx->num_cus * 6 * kBlock;
+    const size_t threads = (size_t)ctx->num_cus * 8 * kBlock;
     if (ctx->gstk && ctx->gstk_threads == threads) return PT_OK;
     if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; }
     HIPCHK(ctx, hipMalloc(&ctx->gstk, threads * (size_t)(kMaxTreeDepth + 1 - kLdsDepth) * sizeof(int)));
@@ -537,6 +585,7 @@ void pt_ctx_destroy(pt_ctx *ctx)
     (void)hipFree(ctx->cnt);
     (void)hipHostFree(ctx->h_cnt);
     (void)hipFree(ctx->gstk);
+    (void)hipFree(ctx->slab);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->poll_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -557,6 +606,10 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1024 || value > (1ull << 28)) return fail(ctx, PT_ERR_ARG, "pool size %llu out of [1024, 2^28]",
                                                               (unsigned long long)value);
         ctx->pool = (uint32_t)value;
+        return PT_OK;
+    case PT_OPT_SLAB_BYTES:
+        if (value < (1ull << 20)) return fail(ctx, PT_ERR_ARG, "sample slab budget below 1 MiB");
+        ctx->slab_budget = value;
         return PT_OK;
     case PT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return PT_OK;
     case PT_OPT_TIME_EXTEND: ctx->time_extend = value != 0; return PT_OK;
@@ -902,86 +955,108 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
     if ((rc = ensure_gstk(ctx)) != PT_OK) return rc;
 
     const uint32_t P = ctx->pool, W = ctx->W, H = ctx->H;
-    const uint64_t total = (uint64_t)W * H * spp_count;
+    const uint32_t npix = W * H;
     const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
     hipStream_t st = ctx->stream;
 
-    Counters init{};
-    init.total_samples = total;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cnt, &init, sizeof init, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));   // init is a stack object
-    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
+    // sample slab: as many samples per pixel as the budget allows; the samples of a call are rendered slab by slab
+    const uint64_t per_sample = (uint64_t)npix * sizeof(float4);
+    uint64_t slab_samples = std::max<uint64_t>(1, ctx->slab_budget / per_sample);
+    slab_samples = std::min<uint64_t>(slab_samples, std::max<uint64_t>(1, spp_count));
+    if (ctx->slab_bytes < slab_samples * per_sample) {
+        if (ctx->slab) { (void)hipFree(ctx->slab); ctx->slab = nullptr; ctx->slab_bytes = 0; }
+        HIPCHK(ctx, hipMalloc(&ctx->slab, slab_samples * per_sample));
+        ctx->slab_bytes = slab_samples * per_sample;
+    }
 
-    const int gs = stream_grid(ctx, P);
-    const uint64_t min_iters = (total + P - 1) / P;
-    uint64_t it = 0;
+    pt_stats acc{};
     size_t ev_used = 0;
-    bool done = total == 0;
-    int cur = 0;       // buffer holding the extended rays
-    while (!done) {
-        PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
-        if (it > 0) {
-            hipLaunchKernelGGL(k_logic, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, ctx->cnt, ctx->queues, P, ctx->film,
-                               (float)spp_total, s0, s1);
-            hipLaunchKernelGGL(k_shade<0>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-            hipLaunchKernelGGL(k_shade<1>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-            hipLaunchKernelGGL(k_shade<2>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-            hipLaunchKernelGGL(k_shade<3>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-        }
-        hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)spp_begin,
-                           s0, s1);
-        hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
-        if (ctx->time_extend) {
-            while (ctx->events.size() < ev_used + 2) {
-                hipEvent_t ev;
-                HIPCHK(ctx, hipEventCreate(&ev));
-                ctx->events.push_back(ev);
+    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
+    const int gs = stream_grid(ctx, P);
+
+    for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
+        const uint64_t first = spp_begin + done_samples;
+        const uint64_t count = std::min<uint64_t>(slab_samples, spp_count - done_samples);
+        const uint64_t total = (uint64_t)npix * count;
+
+        Counters init{};
+        init.total_samples = total;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->cnt, &init, sizeof init, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));   // init is a stack object
+
+        const uint64_t min_iters = (total + P - 1) / P;
+        uint64_t it = 0;
+        bool done = false;
+        int cur = 0;       // buffer holding the extended rays
+        while (!done) {
+            PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
+            if (it > 0) {
+                hipLaunchKernelGGL(k_logic, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, ctx->cnt, ctx->queues, P, ctx->slab,
+                                   (uint32_t)first, npix, (float)spp_total, s0, s1);
+                hipLaunchKernelGGL(k_shade<0>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+                hipLaunchKernelGGL(k_shade<1>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+                hipLaunchKernelGGL(k_shade<2>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
+                hipLaunchKernelGGL(k_shade<3>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
             }
-            HIPCHK(ctx, hipEventRecord(ctx->events[ev_used], st));
-        }
-        rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hit, B.t);
-        if (rc != PT_OK) return rc;
-        if (ctx->time_extend) {
-            HIPCHK(ctx, hipEventRecord(ctx->events[ev_used + 1], st));
-            ev_used += 2;
-        }
-        cur ^= 1;
-        it++;
-        if (it >= min_iters) {
-            // poll the device counters two iterations behind the launch front
-            const int slot = (int)(it & 3);
-            HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[slot], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipEventRecord(ctx->poll_ev[slot], st));
-            if (it >= min_iters + 2) {
-                const int old = (int)((it - 2) & 3);
-                HIPCHK(ctx, hipEventSynchronize(ctx->poll_ev[old]));
-                const Counters &c = ctx->h_cnt[old];
-                if (c.n_in == 0 && c.next_sample >= c.total_samples) done = true;
+            hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
+                               s1);
+            hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
+            if (ctx->time_extend) {
+                while (ctx->events.size() < ev_used + 2) {
+                    hipEvent_t ev;
+                    HIPCHK(ctx, hipEventCreate(&ev));
+                    ctx->events.push_back(ev);
+                }
+                HIPCHK(ctx, hipEventRecord(ctx->events[ev_used], st));
+            }
+            rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hit, B.t);
+            if (rc != PT_OK) return rc;
+            if (ctx->time_extend) {
+                HIPCHK(ctx, hipEventRecord(ctx->events[ev_used + 1], st));
+                ev_used += 2;
+            }
+            cur ^= 1;
+            it++;
+            if (it >= min_iters) {
+                // poll the device counters two iterations behind the launch front
+                const int slot = (int)(it & 3);
+                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[slot], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipEventRecord(ctx->poll_ev[slot], st));
+                if (it >= min_iters + 2) {
+                    const int old = (int)((it - 2) & 3);
+                    HIPCHK(ctx, hipEventSynchronize(ctx->poll_ev[old]));
+                    const Counters &c = ctx->h_cnt[old];
+                    if (c.n_in == 0 && c.next_sample >= c.total_samples) done = true;
+                }
             }
         }
+        // every path of this slab has ended and stored its contribution: fold the slab into the film
+        hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count, npix,
+                           ctx->film);
+        HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[0], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipGetLastError());
+        const Counters &c = ctx->h_cnt[0];
+        acc.rays += c.rays_total;
+        acc.paths += c.paths_total;
+        acc.iterations += c.iter;
+        acc.extend_launches += c.extend_nonempty;
+        acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
-    HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[0], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipGetLastError());
     if (stats) {
-        std::memset(stats, 0, sizeof *stats);
-        const Counters &c = ctx->h_cnt[0];
-        stats->rays = c.rays_total;
-        stats->paths = c.paths_total;
-        stats->iterations = c.iter;
-        stats->extend_launches = c.extend_nonempty;
-        stats->nodes = c.trav[0]; stats->tris = c.trav[1]; stats->leaves = c.trav[2];
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
-        stats->ms_total = ms;
+        acc.ms_total = ms;
         double ext = 0;
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float e = 0;
             HIPCHK(ctx, hipEventElapsedTime(&e, ctx->events[i], ctx->events[i + 1]));
             ext += e;
         }
-        stats->ms_extend = ext;
+        acc.ms_extend = ext;
+        *stats = acc;
     }
     return PT_OK;
 }

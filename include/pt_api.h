@@ -115,6 +115,8 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_POOL_SIZE        1   /* path slots in flight; the reference fixes 0x200000 (src/render.cuh:14) */
 #define PT_OPT_COUNT_TRAVERSAL  2   /* 1: extend counts nodes/triangles/leaves (slower; for roofline bookkeeping) */
 #define PT_OPT_TIME_EXTEND      3   /* 1 (default): bracket every extend launch with HIP events */
+#define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
+                                       samples beyond it are rendered slab after slab */
 
 /* No reference counterpart (the reference uses process-global device symbols, src/render.cu:47,91). */
 int  pt_ctx_create(int device_ordinal, pt_ctx **out);
@@ -152,7 +154,8 @@ int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcp
 /* Replaces render_scene (reference src/render.cuh:50, src/render.cu:244-280): accumulates samples
  * [spp_begin, spp_begin+spp_count) of every pixel, each weighted 1/spp_total, into the bound film and returns
  * when the device is done.  Splitting [0, spp_total) over several calls, contexts or GPUs and summing the films
- * gives the same image as one call (up to float addition order). */
+ * gives the same image as one call (up to float addition order).  Needs width*height*16 bytes of device memory per
+ * sample per pixel rendered at a time (see PT_OPT_SLAB_BYTES). */
 int  pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint64_t seed,
                pt_stats *stats);
 

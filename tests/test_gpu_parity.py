@@ -174,6 +174,44 @@ def test_render_small_pool_many_iterations(pkg, ctx):
     assert np.allclose(small, big, rtol=1e-5, atol=1e-6)
 
 
+def test_render_in_several_slabs(pkg, ctx):
+    """A contribution slab that holds fewer samples than the call renders: the call proceeds slab after slab and the
+    film is the same (per-pixel sums are taken per slab, so equal up to float addition order)."""
+    W, H, spp = 64, 48, 6
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=9)
+    one = ctx.film_download()
+    again = None
+    ctx.film_clear()
+    ctx.render(0, spp, spp, seed=9)
+    again = ctx.film_download()
+    assert np.array_equal(one, again), "the film is not reproducible bit for bit"
+    ctx.film_clear()
+    with pytest.raises(pkg.PtError):
+        ctx.set_option(pkg.OPT_SLAB_BYTES, 16)
+    c2 = pkg.Context(0)
+    c2.upload(scene)
+    c2.film_bind(W, H)
+    c2.set_option(pkg.OPT_SLAB_BYTES, 1 << 20)          # 1 MiB = 21 samples of 64x48 ... use a larger film below
+    c2.close()
+    W2, H2 = 256, 192                                    # 768 KiB per sample: a 1 MiB slab holds one sample
+    scene2 = S.knot_scene(pkg, W2, H2)
+    c3 = pkg.Context(0)
+    c3.upload(scene2)
+    c3.film_bind(W2, H2)
+    c3.render(0, 3, 3, seed=4)
+    ref = c3.film_download()
+    c3.film_clear()
+    c3.set_option(pkg.OPT_SLAB_BYTES, 1 << 20)
+    st = c3.render(0, 3, 3, seed=4)
+    got = c3.film_download()
+    c3.close()
+    assert st.paths == W2 * H2 * 3
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+
+
 def test_traversal_counters_match_oracle(pkg, ctx):
     """Inner nodes visited, triangles tested and leaves entered are per-ray deterministic: the sums must be equal."""
     W, H = 48, 32
