@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "balls"])
     ap.add_argument("--pool", type=int, default=0, help="path slots in flight (0: library default)")
+    ap.add_argument("--extend-mode", type=int, default=2, help="2 single-loop streaming (default), 0 loop-per-phase persistent, 1 plain batches")
+    ap.add_argument("--tune", default="", help="comma list of option=value pairs passed to pt_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -73,6 +75,10 @@ def main():
     ctx = pkg.Context(local_rank)
     if args.pool:
         ctx.set_option(pkg.OPT_POOL_SIZE, args.pool)
+    ctx.set_option(pkg.OPT_EXTEND_MODE, args.extend_mode)
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        ctx.set_option(int(k), int(v))
     ctx.upload(scene)
     film = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
     ctx.film_bind(args.width, args.height, film.data_ptr())

@@ -52,8 +52,12 @@ struct DPlane { float4 pos; float4 nrm; float4 mat; uint32_t type; uint32_t pad[
 struct DSphere { float4 pos_r; float4 mat; uint32_t type; uint32_t pad[3]; };            // 48 B
 
 struct DScene {
-    const float4 *nodes;     // 4 float4 per node: left xy box, right xy box, both z ranges, (left, right, 0, 0)
-    const float4 *tris;      // 4 float4 per triangle: Woop rows z, x, y and (prim id, last-in-leaf flag, 0, 0)
+    // 64 B records.  [0, first_tri): inner nodes = left xy box, right xy box, both z ranges, (left ref, right ref, 0, 0);
+    // [first_tri, ...): triangles = Woop rows z, x, y and (prim id, flags: 1 = last of its leaf, 2 = null record, 0, 0).
+    // A ref is a record index; refs >= first_tri are leaves.
+    const float4 *recs;
+    uint32_t first_tri;
+    uint32_t stack_slots;    // traversal stack slots a ray can need: tree depth + 1
     const DPlane *planes;
     const DSphere *spheres;
     uint32_t num_planes, num_spheres, has_bvh, mesh_type;

@@ -28,13 +28,12 @@
 
 #include "pt_api.h"
 #include "pt_device.h"
+#include "pt_extend.h"
 
 using namespace ptd;
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kLdsDepth = 16;          // traversal stack entries kept in LDS per lane; deeper entries go to global
 constexpr uint32_t kDefaultPool = 1u << 22;
 
 struct PathBuf {
@@ -61,102 +60,6 @@ struct Counters {
 __device__ __forceinline__ int mat_slot(uint32_t type)
 {
     return type == PT_DIFFUSE ? 0 : (type == PT_GLOSSY ? 1 : (type == PT_MIRROR ? 2 : (type == PT_GLASS ? 3 : 0)));
-}
-
-// --------------------------------------------------------------------------------------------------------------
-// extend: closest hit (reference src/render.cu:11-44, src/bvh.cuh:130-189)
-// --------------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool CANON>
-__device__ __forceinline__ void traverse(const DScene &sc, f3 o, f3 d, Hit &h, int (*stk)[kBlock], int *gstk,
-                                         uint32_t gstride, uint32_t gtid, unsigned long long *cnt3)
-{
-    const int tid = threadIdx.x;
-    f3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-    f3 ood = {inv.x * o.x, inv.y * o.y, inv.z * o.z};
-    f3 nood = {ood.x != ood.x ? fl(0x7FC00000) : -ood.x, ood.y != ood.y ? fl(0x7FC00000) : -ood.y,
-               ood.z != ood.z ? fl(0x7FC00000) : -ood.z};
-    int sp = 0;
-    int node = 0;
-    uint32_t c_nodes = 0, c_tris = 0, c_leaves = 0;
-
-    auto push = [&](int v) {
-        if (sp < kLdsDepth) stk[sp][tid] = v;
-        else gstk[(size_t)(sp - kLdsDepth) * gstride + gtid] = v;
-        sp++;
-    };
-    auto pop = [&]() -> int {
-        if (sp == 0) return kSentinel;
-        sp--;
-        return sp < kLdsDepth ? stk[sp][tid] : gstk[(size_t)(sp - kLdsDepth) * gstride + gtid];
-    };
-
-    while (node != kSentinel) {
-        while ((unsigned)node < (unsigned)kSentinel) {      // inner node
-            const float4 *np = sc.nodes + (size_t)node * 4;
-            const float4 lxy = np[0], rxy = np[1], z = np[2];
-            const int2 ch = *reinterpret_cast<const int2 *>(np + 3);
-            if (COUNT) c_nodes++;
-            float t0l, t0r;
-            bool hl = hit_aabb<CANON>(inv, nood, lxy.x, lxy.y, lxy.z, lxy.w, z.x, z.y, h.t, t0l);
-            bool hr = hit_aabb<CANON>(inv, nood, rxy.x, rxy.y, rxy.z, rxy.w, z.z, z.w, h.t, t0r);
-            if (hl || hr) {
-                int far_child = ch.y;
-                node = hl ? ch.x : ch.y;
-                if (hl && hr) {
-                    if (t0r < t0l) { far_child = node; node = ch.y; }
-                    push(far_child);
-                }
-            } else {
-                node = pop();
-            }
-        }
-        while (node < 0) {                                   // leaf: run of triangle records
-            if (COUNT) c_leaves++;
-            const float4 *tp = sc.tris + (size_t)(~node) * 4;
-            for (;;) {
-                const float4 v00 = tp[0], v11 = tp[1], v22 = tp[2];
-                const uint2 meta = *reinterpret_cast<const uint2 *>(tp + 3);
-                if (COUNT && !(meta.y & 2u)) c_tris++;
-                hit_triangle(v00, v11, v22, meta.x, o, d, h);
-                if (meta.y & 1u) break;
-                tp += 4;
-            }
-            node = pop();
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&cnt3[0], (unsigned long long)c_nodes);
-        atomicAdd(&cnt3[1], (unsigned long long)c_tris);
-        atomicAdd(&cnt3[2], (unsigned long long)c_leaves);
-    }
-}
-
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_extend(DScene sc, const float4 *__restrict__ ro,
-                                                   const float4 *__restrict__ rd, const Counters *cnt,
-                                                   uint32_t n_fixed, float4 *__restrict__ hit_out,
-                                                   float *__restrict__ t_out, int *gstk, unsigned long long *cnt3)
-{
-    __shared__ int stk[kLdsDepth][kBlock];
-    const uint32_t n = cnt ? cnt->n_in : n_fixed;
-    const uint32_t stride = gridDim.x * kBlock;
-    const uint32_t gtid = blockIdx.x * kBlock + threadIdx.x;
-    for (uint32_t i = gtid; i < n; i += stride) {
-        const float4 o4 = ro[i], d4 = rd[i];
-        const f3 o = xyz(o4), d = xyz(d4);
-        Hit h;
-        h.t = kFltMax; h.prim = PT_PRIM_MISS; h.n = mk3(0, 0, 0);
-        for (uint32_t k = 0; k < sc.num_planes; k++) hit_plane(sc.planes[k], k, o, d, h);
-        for (uint32_t k = 0; k < sc.num_spheres; k++) hit_sphere(sc.spheres[k], k, o, d, h);
-        if (sc.has_bvh) {
-            // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
-            if (__any(slab_degenerate(d))) traverse<COUNT, true>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
-            else traverse<COUNT, false>(sc, o, d, h, stk, gstk, stride, gtid, cnt3);
-        }
-        f3 nn = h.prim == PT_PRIM_MISS ? mk3(0, 0, 0) : normalize3(h.n);     // reference src/render.cu:41
-        hit_out[i] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(h.prim));
-        t_out[i] = h.t;
-    }
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -420,6 +323,8 @@ struct pt_ctx {
     uint32_t pool = kDefaultPool;
     bool count_traversal = false;
     bool time_extend = true;
+    int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
+    int refill_idle = kRefillIdle;
 
     // film
     float *film = nullptr;
@@ -437,8 +342,6 @@ struct pt_ctx {
     uint32_t *queues = nullptr;
     Counters *cnt = nullptr;
     Counters *h_cnt = nullptr;     // pinned, 4 slots
-    int *gstk = nullptr;
-    size_t gstk_threads = 0;
     std::vector<hipEvent_t> events;
     hipEvent_t poll_ev[4]{};
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -465,28 +368,11 @@ static int fail(pt_ctx *ctx, int code, const char *fmt, ...)
             return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-static int extend_grid(const pt_ctx *ctx, uint64_t n)
-{
-    // 16 KB of LDS per block and 40 VGPRs admit 8 blocks of 256 threads (32 waves) per CU
-    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
-    const uint64_t need = (n + kBlock - 1) / kBlock;
-    return (int)std::max<uint64_t>(1, std::min(cap, need));
-}
 static int stream_grid(const pt_ctx *ctx, uint64_t n)
 {
     const uint64_t cap = (uint64_t)ctx->num_cus * 8;
     const uint64_t need = (n + kBlock - 1) / kBlock;
     return (int)std::max<uint64_t>(1, std::min(cap, need));
-}
-
-static int ensure_gstk(pt_ctx *ctx)
-{
-    const size_t threads = (size_t)ctx->num_cus * 8 * kBlock;
-    if (ctx->gstk && ctx->gstk_threads == threads) return PT_OK;
-    if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; }
-    HIPCHK(ctx, hipMalloc(&ctx->gstk, threads * (size_t)(kMaxTreeDepth + 1 - kLdsDepth) * sizeof(int)));
-    ctx->gstk_threads = threads;
-    return PT_OK;
 }
 
 static void free_pool(pt_ctx *ctx)
@@ -537,6 +423,49 @@ template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const
     return PT_OK;
 }
 
+// LDS stack slots per lane -> blocks of 256 threads a CU can hold (160 KB of LDS, at most 8 blocks by waves)
+static int blocks_per_cu(int stack_slots) { return std::max(1, std::min(8, 160 / stack_slots)); }
+
+template <int STACK>
+static void launch_extend_stack(pt_ctx *ctx, int grid, const ExtendArgs &a)
+{
+    const bool count = ctx->count_traversal;
+    if (ctx->extend_mode == 1) {
+        if (count) hipLaunchKernelGGL((k_extend_batch<STACK, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
+        else hipLaunchKernelGGL((k_extend_batch<STACK, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
+    } else {
+        if (count) hipLaunchKernelGGL((k_extend_stream<STACK, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
+        else hipLaunchKernelGGL((k_extend_stream<STACK, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
+    }
+}
+
+static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const Counters *cnt, uint32_t n_fixed,
+                         uint32_t n_upper, float4 *hit, float *t)
+{
+    ExtendArgs a{};
+    a.ro = ro; a.rd = rd;
+    a.n_ptr = cnt ? &cnt->n_in : nullptr;
+    a.n_fixed = n_fixed;
+    a.hit_out = hit; a.t_out = t;
+    a.cnt3 = &ctx->cnt->trav[0];
+    a.refill_idle = ctx->refill_idle;
+    // smallest stack that holds the scene's tree; it decides how many blocks share a CU's LDS
+    const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
+    const int stack = need <= 16 ? 16 : (need <= 24 ? 24 : (need <= 32 ? 32 : (need <= 48 ? 48 : 64)));
+    const uint64_t cap = (uint64_t)ctx->num_cus * blocks_per_cu(stack);
+    const uint64_t want = ((uint64_t)n_upper + kBlock - 1) / kBlock;
+    const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
+    switch (stack) {
+    case 16: launch_extend_stack<16>(ctx, grid, a); break;
+    case 24: launch_extend_stack<24>(ctx, grid, a); break;
+    case 32: launch_extend_stack<32>(ctx, grid, a); break;
+    case 48: launch_extend_stack<48>(ctx, grid, a); break;
+    default: launch_extend_stack<64>(ctx, grid, a); break;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PT_OK;
+}
+
 extern "C" {
 
 int pt_ctx_create(int device, pt_ctx **out)
@@ -584,7 +513,6 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (ctx->film_owned) (void)hipFree(ctx->film);
     (void)hipFree(ctx->cnt);
     (void)hipHostFree(ctx->h_cnt);
-    (void)hipFree(ctx->gstk);
     (void)hipFree(ctx->slab);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
     for (auto ev : ctx->poll_ev) if (ev) (void)hipEventDestroy(ev);
@@ -613,6 +541,14 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         return PT_OK;
     case PT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return PT_OK;
     case PT_OPT_TIME_EXTEND: ctx->time_extend = value != 0; return PT_OK;
+    case PT_OPT_EXTEND_MODE:
+        if (value != 1 && value != 2) return fail(ctx, PT_ERR_ARG, "extend mode %llu unknown", (unsigned long long)value);
+        ctx->extend_mode = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_REFILL_IDLE:
+        if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
+        ctx->refill_idle = (int)value;
+        return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
 }
@@ -625,17 +561,16 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
     free_scene(ctx);
     DScene sc{};
 
-    // ---- mesh: re-lay the reference's node + float4-run buffers into 64 B node / 64 B triangle records ----------
-    std::vector<float4> nodes, recs;
+    // ---- mesh: re-lay the reference's node + float4-run buffers into one array of 64 B records --------------------
+    // records [0, N) are the inner nodes with their child references rewritten to record indices, records [N, ...)
+    // the triangles; record N is a triangle nothing can hit, standing in for empty leaves.
     if (s->bvh_nodes && s->num_nodes > 0) {
         if (!s->bvh_tris || s->num_tri_float4 < 2) return fail(ctx, PT_ERR_ARG, "mesh without triangle buffer");
-        if (s->num_nodes >= (uint64_t)kSentinel || s->num_tri_float4 >= (1ull << 31))
-            return fail(ctx, PT_ERR_ARG, "mesh too large for 31-bit node/triangle references");
         const uint64_t N = s->num_nodes, M = s->num_tri_float4;
-        nodes.resize(N * 4);
-        std::memcpy(nodes.data(), s->bvh_nodes, N * 64);
-        recs.reserve((size_t)(s->num_tris + 1) * 4);
-        // record 0: a triangle nothing can hit, standing in for empty leaves
+        if (N + M / 3 + 2 >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
+        std::vector<float4> recs(N * 4);
+        std::memcpy(recs.data(), s->bvh_nodes, N * 64);
+        recs.reserve((size_t)(N + s->num_tris + 1) * 4);
         recs.push_back(make_float4(0, 0, 0, 0)); recs.push_back(make_float4(0, 0, 0, 0));
         recs.push_back(make_float4(0, 0, 0, 0));
         {
@@ -646,13 +581,14 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
         }
         const float *tf = s->bvh_tris;
         auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+        std::vector<uint8_t> is_node_child(N, 0);
         for (uint64_t i = 0; i < N; i++) {
             int32_t ch[2];
-            std::memcpy(ch, &nodes[i * 4 + 3], 8);
+            std::memcpy(ch, &recs[i * 4 + 3], 8);
             for (int c = 0; c < 2; c++) {
                 if (ch[c] >= 0) {
-                    if ((uint64_t)ch[c] >= N) return fail(ctx, PT_ERR_ARG, "node %llu: child %d out of range",
-                                                          (unsigned long long)i, ch[c]);
+                    if ((uint64_t)ch[c] >= N || ch[c] == 0) return fail(ctx, PT_ERR_ARG, "node %llu: child %d out of range",
+                                                                        (unsigned long long)i, ch[c]);
                     continue;
                 }
                 uint64_t a = (uint64_t)(uint32_t)~ch[c];
@@ -674,42 +610,42 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                     recs.push_back(meta);
                     count++;
                 }
-                int32_t ref;
                 if (count == 0) {
-                    ref = ~0;
+                    ch[c] = (int32_t)N;
                 } else {
                     uint32_t m[2];
                     std::memcpy(m, &recs[recs.size() - 1], 8);
                     m[1] |= 1u;
                     std::memcpy(&recs[recs.size() - 1], m, 8);
-                    ref = ~(int32_t)first;
+                    ch[c] = (int32_t)first;
                 }
-                ch[c] = ref;
             }
-            std::memcpy(&nodes[i * 4 + 3], ch, 8);
+            std::memcpy(&recs[i * 4 + 3], ch, 8);
         }
-        // depth check: the traversal stack holds kMaxTreeDepth entries (the reference's STACK_SIZE, src/bvh.cuh:12)
+        // depth: a ray's traversal stack needs one slot per level plus the sentinel; the reference's own stack has 64
+        // entries (src/bvh.cuh:12)
+        uint32_t maxd = 0;
         {
             std::vector<std::pair<uint32_t, uint32_t>> st;
             st.push_back({0u, 1u});
             uint64_t visited = 0;
-            uint32_t maxd = 0;
             while (!st.empty()) {
                 auto [ni, dep] = st.back();
                 st.pop_back();
                 if (++visited > N) return fail(ctx, PT_ERR_ARG, "node graph is not a tree");
                 maxd = std::max(maxd, dep);
                 int32_t ch[2];
-                std::memcpy(ch, &nodes[(size_t)ni * 4 + 3], 8);
+                std::memcpy(ch, &recs[(size_t)ni * 4 + 3], 8);
                 for (int c = 0; c < 2; c++)
-                    if (ch[c] >= 0) st.push_back({(uint32_t)ch[c], dep + 1});
+                    if ((uint64_t)ch[c] < N) st.push_back({(uint32_t)ch[c], dep + 1});
             }
             if (maxd > (uint32_t)kMaxTreeDepth)
                 return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
         }
         int rc;
-        if ((rc = upload(ctx, nodes, &sc.nodes)) != PT_OK) return rc;
-        if ((rc = upload(ctx, recs, &sc.tris)) != PT_OK) return rc;
+        if ((rc = upload(ctx, recs, &sc.recs)) != PT_OK) return rc;
+        sc.first_tri = (uint32_t)N;
+        sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
         sc.mesh_type = s->mesh_material_type;
         sc.mesh_mat = make_float4(s->mesh_material[0], s->mesh_material[1], s->mesh_material[2], s->mesh_material[3]);
@@ -764,23 +700,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
     sc.cam = s->camera;
     ctx->sc = sc;
     ctx->have_scene = true;
-    return PT_OK;
-}
-
-static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const Counters *cnt, uint32_t n_fixed,
-                         uint32_t n_upper, float4 *hit, float *t)
-{
-    int rc = ensure_gstk(ctx);
-    if (rc != PT_OK) return rc;
-    const int grid = extend_grid(ctx, n_upper);
-    unsigned long long *c3 = &ctx->cnt->trav[0];
-    if (ctx->count_traversal)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, ro, rd, cnt, n_fixed, hit,
-                           t, ctx->gstk, c3);
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, ro, rd, cnt, n_fixed, hit,
-                           t, ctx->gstk, c3);
-    HIPCHK(ctx, hipGetLastError());
     return PT_OK;
 }
 
@@ -952,7 +871,6 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx);
     if (rc != PT_OK) return rc;
-    if ((rc = ensure_gstk(ctx)) != PT_OK) return rc;
 
     const uint32_t P = ctx->pool, W = ctx->W, H = ctx->H;
     const uint32_t npix = W * H;

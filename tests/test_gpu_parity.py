@@ -53,6 +53,24 @@ def test_intersect_matches_oracle_on_shipped_meshes(pkg, ctx, mesh, cam):
     assert (prim != O.PRIM_MISS).mean() > 0.3
 
 
+def test_both_extend_kernels_give_identical_hits(pkg, ctx):
+    """The plain batch kernel and the persistent slot-refilling kernel must agree bit for bit with the fixture."""
+    scene = S.parity_cases(pkg)["knot"]
+    g = np.load(os.path.join(GOLDEN, "rays_knot.npz"))
+    ctx.upload(scene)
+    reps = 40                                   # enough rays that persistent waves refill many times
+    org = np.tile(g["org"], (reps, 1))
+    dir_ = np.tile(g["dir"], (reps, 1))
+    try:
+        for mode in (1, 0, 2, 3):
+            ctx.set_option(pkg.OPT_EXTEND_MODE, mode)
+            t, prim, _ = ctx.intersect(org, dir_)
+            assert np.array_equal(prim, np.tile(g["prim"], reps)), "mode %d" % mode
+            assert np.array_equal(t, np.tile(g["t"], reps)), "mode %d" % mode
+    finally:
+        ctx.set_option(pkg.OPT_EXTEND_MODE, 2)
+
+
 def test_primary_rays_bit_exact(pkg, ctx):
     """generate stage: same counter-based random numbers, same arithmetic -> identical camera rays (thin lens on)."""
     for W, H in [(48, 32), (50, 30)]:         # tiled and untiled pixel enumeration
