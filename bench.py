@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "balls"])
     ap.add_argument("--pool", type=int, default=0, help="path slots in flight (0: library default)")
-    ap.add_argument("--extend-mode", type=int, default=2, help="2 single-loop streaming (default), 0 loop-per-phase persistent, 1 plain batches")
+    ap.add_argument("--extend-mode", type=int, default=2, help="2 persistent single-step waves (default), 1 loop-per-phase batches")
     ap.add_argument("--tune", default="", help="comma list of option=value pairs passed to pt_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

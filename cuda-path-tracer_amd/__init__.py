@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 DIFFUSE, MIRROR, GLOSSY, GLASS = 0x4, 0x8, 0x10, 0x20
 PRIM_MISS, PRIM_PLANE, PRIM_SPHERE = 0xFFFFFFFF, 0x80000000, 0x40000000
 OPT_POOL_SIZE, OPT_COUNT_TRAVERSAL, OPT_TIME_EXTEND, OPT_SLAB_BYTES, OPT_EXTEND_MODE = 1, 2, 3, 4, 5
-OPT_TUNE_REFILL_IDLE, OPT_TUNE_TRI_LANES = 6, 7
+OPT_TUNE_REFILL_IDLE, OPT_TUNE_LDS_SLOTS = 6, 7
 
 
 class Plane(C.Structure):

@@ -29,10 +29,12 @@ struct ExtendArgs {
     const float4 *rd;          // ray directions (xyz)
     const uint32_t *n_ptr;     // ray count on the device, or NULL
     uint32_t n_fixed;          // ray count when n_ptr is NULL
-    float4 *hit_out;           // unit normal xyz, w = prim id bits
+    uint32_t *hid_out;         // hit id: PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, triangle record index, or PT_PRIM_MISS
     float *t_out;              // hit distance, FLT_MAX on a miss
     unsigned long long *cnt3;  // nodes, triangles, leaves (COUNT only)
     int refill_idle;
+    int lds_slots;             // traversal stack slots per lane kept in LDS
+    int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
 };
 
 // Per-lane traversal state.  The hit is kept as (t, hid): hid = PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, the record index of
@@ -45,7 +47,40 @@ struct RayState {
     uint32_t c_nodes, c_tris, c_leaves;
 };
 
-__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, int *stk_col)
+// A lane's traversal stack: slot s lives at lds[s * kBlock] (a column of the block's LDS array) while s < lds_slots and,
+// in kernels built with OVERFLOW, in a global array beyond that.  Trees shallow enough for LDS alone use the kernels
+// without the overflow test.
+template <bool OVERFLOW>
+struct Stack {
+    int *lds;
+    int *glob;
+    int lds_slots;
+    uint32_t gstride;
+    __device__ __forceinline__ void put(int slot, int v) const
+    {
+        if (!OVERFLOW || slot < lds_slots) lds[slot * kBlock] = v;
+        else __builtin_nontemporal_store(v, glob + (size_t)(slot - lds_slots) * gstride);
+    }
+    __device__ __forceinline__ int get(int slot) const
+    {
+        if (!OVERFLOW || slot < lds_slots) return lds[slot * kBlock];
+        return __builtin_nontemporal_load(glob + (size_t)(slot - lds_slots) * gstride);
+    }
+};
+
+template <bool OVERFLOW>
+__device__ __forceinline__ Stack<OVERFLOW> make_stack(int *lds_base, const ExtendArgs &a)
+{
+    Stack<OVERFLOW> s;
+    s.lds = lds_base + threadIdx.x;
+    s.gstride = gridDim.x * kBlock;
+    s.glob = OVERFLOW ? a.gstk + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
+    s.lds_slots = a.lds_slots;
+    return s;
+}
+
+template <class STK>
+__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, const STK &stk)
 {
     R.o = o;
     R.d = d;
@@ -59,38 +94,43 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f
     const f3 ood = {R.inv.x * o.x, R.inv.y * o.y, R.inv.z * o.z};
     R.nood = mk3(ood.x != ood.x ? fl(0x7FC00000) : -ood.x, ood.y != ood.y ? fl(0x7FC00000) : -ood.y,
                  ood.z != ood.z ? fl(0x7FC00000) : -ood.z);
-    stk_col[0] = kSentinel;                 // bottom slot: popping it ends the traversal
+    stk.put(0, kSentinel);                  // bottom slot: popping it ends the traversal
     R.sp = 1;
     R.node = sc.has_bvh ? 0 : kSentinel;
 }
 
-// Writes the hit record of a finished ray: unit normal (reference src/render.cu:41) + reported primitive id, and t.
-__device__ __forceinline__ void ray_retire(const DScene &sc, const RayState &R, uint32_t ray, float4 *hit_out, float *t_out)
+// Unit normal (reference src/render.cu:41) and reported primitive id of a hit, from the hit id extend stores.  The
+// triangle normal is the cross product of two Woop rows (reference src/bvh.cuh:114), the sphere normal is (p - c) / r
+// at the hit point (reference src/object.cuh:39); both are re-derived here so that traversal carries no normal around.
+__device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f3 d, float t, uint32_t &prim)
 {
     f3 n = mk3(0, 0, 0);
-    uint32_t prim = R.hid;
-    if (R.hid != PT_PRIM_MISS) {
-        if (R.hid & PT_PRIM_PLANE) {
-            n = xyz(sc.planes[R.hid & 0x3FFFFFFFu].nrm);
-        } else if (R.hid & PT_PRIM_SPHERE) {
-            const float4 pr = sc.spheres[R.hid & 0x3FFFFFFFu].pos_r;     // reference src/object.cuh:39
-            const f3 p = {__fmaf_rn(R.d.x, R.t, R.o.x), __fmaf_rn(R.d.y, R.t, R.o.y), __fmaf_rn(R.d.z, R.t, R.o.z)};
-            n = (p - xyz(pr)) / pr.w;
-        } else {
-            const float4 *rec = sc.recs + (size_t)R.hid * 4;               // reference src/bvh.cuh:114
-            n = cross3(xyz(rec[1]), xyz(rec[2]));
-            prim = __float_as_uint(rec[3].x);
-        }
-        n = normalize3(n);
+    prim = hid;
+    if (hid == PT_PRIM_MISS) return n;
+    if (hid & PT_PRIM_PLANE) {
+        n = xyz(sc.planes[hid & 0x3FFFFFFFu].nrm);
+    } else if (hid & PT_PRIM_SPHERE) {
+        const float4 pr = sc.spheres[hid & 0x3FFFFFFFu].pos_r;
+        const f3 p = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
+        n = (p - xyz(pr)) / pr.w;
+    } else {
+        const float4 *rec = sc.recs + (size_t)hid * 4;
+        n = cross3(xyz(rec[1]), xyz(rec[2]));
+        prim = __float_as_uint(rec[3].x);
     }
-    hit_out[ray] = make_float4(n.x, n.y, n.z, __uint_as_float(prim));
+    return normalize3(n);
+}
+
+__device__ __forceinline__ void ray_retire(const RayState &R, uint32_t ray, uint32_t *hid_out, float *t_out)
+{
+    hid_out[ray] = R.hid;
     t_out[ray] = R.t;
 }
 
 // One inner-node step (reference src/bvh.cuh:141-168): test both child boxes, descend into the nearer hit child
 // (ties: left), push the farther one, or pop when neither is hit.
-template <bool COUNT, bool CANON>
-__device__ __forceinline__ void node_step(const DScene &sc, RayState &R, int *stk_col, float4 r0, float4 r1, float4 r2,
+template <bool COUNT, bool CANON, class STK>
+__device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const STK &stk, float4 r0, float4 r1, float4 r2,
                                           float4 r3)
 {
     if (COUNT) R.c_nodes++;
@@ -104,22 +144,21 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, int *st
     next = right_first ? cr : next;
     const int far_child = right_first ? cl : cr;
     if (both) {
-        stk_col[R.sp * kBlock] = far_child;
+        stk.put(R.sp, far_child);
         R.sp++;
     }
     if (!(hl || hr)) {
         R.sp--;
-        next = stk_col[R.sp * kBlock];
+        next = stk.get(R.sp);
     }
     if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
     R.node = next;
 }
 
 // One triangle step (reference src/bvh.cuh:171-187, 93-120): test the record, go on to the next record of the leaf or
-// pop after the last one.  All of the test is evaluated unconditionally; the outcome is the same as the reference's
-// nested early-outs because nothing in it has side effects.
-template <bool COUNT>
-__device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, int *stk_col, float4 v00, float4 v11, float4 v22,
+// pop after the last one.
+template <bool COUNT, class STK>
+__device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const STK &stk, float4 v00, float4 v11, float4 v22,
                                          float4 meta)
 {
     const uint32_t flags = __float_as_uint(meta.y);
@@ -129,19 +168,22 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, int *stk
     const float Dz = __fmaf_rn(d.z, v00.z, __fmaf_rn(d.y, v00.y, d.x * v00.x));
     const float invDz = 1.0f / Dz;
     const float t = Oz * invDz;
-    const float Ox = __fmaf_rn(o.z, v11.z, __fmaf_rn(o.y, v11.y, __fmaf_rn(o.x, v11.x, v11.w)));
-    const float Dx = __fmaf_rn(d.z, v11.z, __fmaf_rn(d.y, v11.y, d.x * v11.x));
-    const float u = __fmaf_rn(t, Dx, Ox);
-    const float Oy = __fmaf_rn(o.z, v22.z, __fmaf_rn(o.y, v22.y, __fmaf_rn(o.x, v22.x, v22.w)));
-    const float Dy = __fmaf_rn(d.z, v22.z, __fmaf_rn(d.y, v22.y, d.x * v22.x));
-    const float v = __fmaf_rn(t, Dy, Oy);
-    const bool hit = (t > kEps) & (t < R.t) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
-    R.t = hit ? t : R.t;
-    R.hid = hit ? (uint32_t)R.node : R.hid;
+    if (t > kEps && t < R.t) {
+        const float Ox = __fmaf_rn(o.z, v11.z, __fmaf_rn(o.y, v11.y, __fmaf_rn(o.x, v11.x, v11.w)));
+        const float Dx = __fmaf_rn(d.z, v11.z, __fmaf_rn(d.y, v11.y, d.x * v11.x));
+        const float u = __fmaf_rn(t, Dx, Ox);
+        const float Oy = __fmaf_rn(o.z, v22.z, __fmaf_rn(o.y, v22.y, __fmaf_rn(o.x, v22.x, v22.w)));
+        const float Dy = __fmaf_rn(d.z, v22.z, __fmaf_rn(d.y, v22.y, d.x * v22.x));
+        const float v = __fmaf_rn(t, Dy, Oy);
+        if ((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f)) {
+            R.t = t;
+            R.hid = (uint32_t)R.node;
+        }
+    }
     int next = R.node + 1;
     if (flags & 1u) {
         R.sp--;
-        next = stk_col[R.sp * kBlock];
+        next = stk.get(R.sp);
         if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
     }
     R.node = next;
@@ -158,56 +200,60 @@ __device__ __forceinline__ void flush_counts(const RayState &R, unsigned long lo
 }
 
 // ---- loop-per-phase traversal of one ray (reference src/bvh.cuh:139-188) -------------------------------------------
-template <bool COUNT, bool CANON>
-__device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, int *stk_col)
+template <bool COUNT, bool CANON, class STK>
+__device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, const STK &stk)
 {
     while (R.node != kSentinel) {
         while ((uint32_t)R.node < sc.first_tri) {
             const float4 *p = sc.recs + (size_t)R.node * 4;
-            node_step<COUNT, CANON>(sc, R, stk_col, p[0], p[1], p[2], p[3]);
+            node_step<COUNT, CANON>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
         while (R.node != kSentinel && (uint32_t)R.node >= sc.first_tri) {
             const float4 *p = sc.recs + (size_t)R.node * 4;
-            tri_step<COUNT>(sc, R, stk_col, p[0], p[1], p[2], p[3]);
+            tri_step<COUNT>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
     }
 }
 
-template <int STACK, bool COUNT>
+extern __shared__ int g_stack_lds[];      // [lds_slots][kBlock], sized at launch
+
+template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a)
 {
-    __shared__ int stk[STACK][kBlock];
-    int *stk_col = &stk[0][threadIdx.x];
+    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
     const uint32_t stride = gridDim.x * kBlock;
     RayState R;
     R.c_nodes = R.c_tris = R.c_leaves = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk_col);
+        ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk);
         // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
-        if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true>(sc, R, stk_col);
-        else traverse_phases<COUNT, false>(sc, R, stk_col);
-        ray_retire(sc, R, i, a.hit_out, a.t_out);
+        if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true>(sc, R, stk);
+        else traverse_phases<COUNT, false>(sc, R, stk);
+        ray_retire(R, i, a.hid_out, a.t_out);
     }
     flush_counts<COUNT>(R, a.cnt3);
 }
 
 // ---- persistent single-step traversal ---------------------------------------------------------------------------------
-template <bool COUNT, bool CANON>
-__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, int *stk_col)
+template <bool COUNT, bool CANON, class STK>
+__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
     if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
-    const float4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
-    if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk_col, r0, r1, r2, r3);
-    else tri_step<COUNT>(sc, R, stk_col, r0, r1, r2, r3);
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    float4 r3 = p[3];
+    // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
+    // references into the node branch, a second memory round trip in every step.
+    asm volatile("" : "+v"(r3.x), "+v"(r3.y));
+    if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
+    else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
 }
 
-template <int STACK, bool COUNT>
+template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs a)
 {
-    __shared__ int stk[STACK][kBlock];
-    int *stk_col = &stk[0][threadIdx.x];
+    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
     const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
     // wave-uniform cursor over this wave's chunks of the ray buffer
@@ -232,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
         if (nidle == 64 || (more_work && nidle >= a.refill_idle)) {
             // retire finished rays, refill their slots
             if (ray != kNoRay && R.node == kSentinel) {
-                ray_retire(sc, R, ray, a.hit_out, a.t_out);
+                ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
             }
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
                 __builtin_amdgcn_mbcnt_hi((uint32_t)(emask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emask, 0));
             if (empty && rank < take) {
                 ray = next + rank;
-                ray_begin(sc, R, xyz(a.ro[ray]), xyz(a.rd[ray]), stk_col);
+                ray_begin(sc, R, xyz(a.ro[ray]), xyz(a.rd[ray]), stk);
                 degenerate = slab_degenerate(R.d);
             }
             next += take;
@@ -259,8 +305,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }
-        if (canon) stream_step<COUNT, true>(sc, R, stk_col);
-        else stream_step<COUNT, false>(sc, R, stk_col);
+        if (canon) stream_step<COUNT, true>(sc, R, stk);
+        else stream_step<COUNT, false>(sc, R, stk);
     }
     flush_counts<COUNT>(R, a.cnt3);
 }

@@ -40,7 +40,7 @@ struct PathBuf {
     float4 *o;      // origin xyz
     float4 *d;      // direction xyz, w = film pixel index bits
     float4 *thr;    // throughput rgb, w = sample index | bounce << 27
-    float4 *hit;    // unit normal xyz, w = prim id bits          (written by extend)
+    uint32_t *hid;  // hit id: plane / sphere / triangle record / miss  (written by extend)
     float *t;       // hit distance, FLT_MAX on a miss            (written by extend)
 };
 
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_logic(DScene sc, PathBuf A, Counters
                             A.thr[i] = th;
                         }
                     }
-                    if (alive) slot = mat_slot(material_type_of(sc, __float_as_uint(A.hit[i].w)));
+                    if (alive) slot = mat_slot(material_type_of(sc, A.hid[i]));
                 }
             }
             slots[b] = slot;
@@ -171,15 +171,17 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PathBuf A, PathBuf 
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
         const uint32_t i = queues[(size_t)MAT * P + j];
-        const float4 o4 = A.o[i], d4 = A.d[i], h4 = A.hit[i];
+        const float4 o4 = A.o[i], d4 = A.d[i];
+        const uint32_t hid = A.hid[i];
         float4 th = A.thr[i];
         const float t = A.t[i];
         const uint32_t pixel = __float_as_uint(d4.w);
         const uint32_t sk = __float_as_uint(th.w);
         const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-        const uint32_t prim = __float_as_uint(h4.w);
-        const float4 mat = material_of(sc, prim);
-        const f3 o = xyz(o4), d = xyz(d4), n3 = xyz(h4);
+        const float4 mat = material_of(sc, hid);
+        const f3 o = xyz(o4), d = xyz(d4);
+        uint32_t prim;
+        const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
         const f3 hitp = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
         Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
         f3 out;
@@ -286,6 +288,18 @@ __global__ __launch_bounds__(kBlock) void k_film_reduce(const float4 *__restrict
     }
 }
 
+// hit ids -> (unit normal, reported primitive id) for the closest-hit entry points
+__global__ __launch_bounds__(kBlock) void k_hit_expand(DScene sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
+                                                       const uint32_t *__restrict__ hid, const float *__restrict__ t,
+                                                       uint32_t n, float4 *__restrict__ hit4)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        uint32_t prim;
+        const f3 nn = hit_normal(sc, hid[i], xyz(ro[i]), xyz(rd[i]), t[i], prim);
+        hit4[i] = make_float4(nn.x, nn.y, nn.z, __uint_as_float(prim));
+    }
+}
+
 // camera rays of one sample index in film-pixel order (parity check of the generate stage)
 __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, uint32_t sample, uint32_t seed0,
                                                     uint32_t seed1, float4 *__restrict__ ro, float4 *__restrict__ rd)
@@ -325,6 +339,11 @@ struct pt_ctx {
     bool time_extend = true;
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
+    int lds_slots = 20;
+    int *gstk = nullptr;
+    size_t gstk_threads = 0;
+    uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
+    size_t tmp_hid_n = 0;
 
     // film
     float *film = nullptr;
@@ -378,7 +397,7 @@ static int stream_grid(const pt_ctx *ctx, uint64_t n)
 static void free_pool(pt_ctx *ctx)
 {
     for (auto &b : ctx->buf) {
-        (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hit); (void)hipFree(b.t);
+        (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hid); (void)hipFree(b.t);
         b = PathBuf{};
     }
     (void)hipFree(ctx->queues);
@@ -395,7 +414,7 @@ static int ensure_pool(pt_ctx *ctx)
         HIPCHK(ctx, hipMalloc(&b.o, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.d, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.thr, P * sizeof(float4)));
-        HIPCHK(ctx, hipMalloc(&b.hit, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.hid, P * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
     }
     HIPCHK(ctx, hipMalloc(&ctx->queues, 4 * P * sizeof(uint32_t)));
@@ -423,45 +442,47 @@ template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const
     return PT_OK;
 }
 
-// LDS stack slots per lane -> blocks of 256 threads a CU can hold (160 KB of LDS, at most 8 blocks by waves)
-static int blocks_per_cu(int stack_slots) { return std::max(1, std::min(8, 160 / stack_slots)); }
-
-template <int STACK>
-static void launch_extend_stack(pt_ctx *ctx, int grid, const ExtendArgs &a)
-{
-    const bool count = ctx->count_traversal;
-    if (ctx->extend_mode == 1) {
-        if (count) hipLaunchKernelGGL((k_extend_batch<STACK, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
-        else hipLaunchKernelGGL((k_extend_batch<STACK, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
-    } else {
-        if (count) hipLaunchKernelGGL((k_extend_stream<STACK, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
-        else hipLaunchKernelGGL((k_extend_stream<STACK, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->sc, a);
-    }
-}
-
+// Traversal stack slots kept in LDS per lane.  20 slots = 20 KB per 256-thread block, so 8 blocks (the wave limit)
+// share a CU's 160 KB; deeper trees keep their first lds_slots slots in LDS and the rest in a global array.
 static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const Counters *cnt, uint32_t n_fixed,
-                         uint32_t n_upper, float4 *hit, float *t)
+                         uint32_t n_upper, uint32_t *hid, float *t)
 {
+    const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
+    const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
+    const bool overflow = need > (uint32_t)lds_slots;
+    const int per_cu = std::max(1, std::min(8, 160 / lds_slots));
+    const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
+    const uint64_t want = ((uint64_t)n_upper + kBlock - 1) / kBlock;
+    const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
+    if (overflow) {
+        const size_t threads = (size_t)ctx->num_cus * 8 * kBlock;
+        if (!ctx->gstk || ctx->gstk_threads != threads) {
+            if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; }
+            HIPCHK(ctx, hipMalloc(&ctx->gstk, threads * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
+            ctx->gstk_threads = threads;
+        }
+    }
     ExtendArgs a{};
     a.ro = ro; a.rd = rd;
     a.n_ptr = cnt ? &cnt->n_in : nullptr;
     a.n_fixed = n_fixed;
-    a.hit_out = hit; a.t_out = t;
+    a.hid_out = hid; a.t_out = t;
     a.cnt3 = &ctx->cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
-    // smallest stack that holds the scene's tree; it decides how many blocks share a CU's LDS
-    const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
-    const int stack = need <= 16 ? 16 : (need <= 24 ? 24 : (need <= 32 ? 32 : (need <= 48 ? 48 : 64)));
-    const uint64_t cap = (uint64_t)ctx->num_cus * blocks_per_cu(stack);
-    const uint64_t want = ((uint64_t)n_upper + kBlock - 1) / kBlock;
-    const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
-    switch (stack) {
-    case 16: launch_extend_stack<16>(ctx, grid, a); break;
-    case 24: launch_extend_stack<24>(ctx, grid, a); break;
-    case 32: launch_extend_stack<32>(ctx, grid, a); break;
-    case 48: launch_extend_stack<48>(ctx, grid, a); break;
-    default: launch_extend_stack<64>(ctx, grid, a); break;
+    a.lds_slots = lds_slots;
+    a.gstk = ctx->gstk;
+    const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
+    const bool count = ctx->count_traversal;
+    const dim3 g(grid), b(kBlock);
+#define PT_LAUNCH(K, OV, CT) hipLaunchKernelGGL((K<OV, CT>), g, b, shmem, ctx->stream, ctx->sc, a)
+    if (ctx->extend_mode == 1) {
+        if (overflow) { if (count) PT_LAUNCH(k_extend_batch, true, true); else PT_LAUNCH(k_extend_batch, true, false); }
+        else { if (count) PT_LAUNCH(k_extend_batch, false, true); else PT_LAUNCH(k_extend_batch, false, false); }
+    } else {
+        if (overflow) { if (count) PT_LAUNCH(k_extend_stream, true, true); else PT_LAUNCH(k_extend_stream, true, false); }
+        else { if (count) PT_LAUNCH(k_extend_stream, false, true); else PT_LAUNCH(k_extend_stream, false, false); }
     }
+#undef PT_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return PT_OK;
 }
@@ -512,6 +533,8 @@ void pt_ctx_destroy(pt_ctx *ctx)
     free_pool(ctx);
     if (ctx->film_owned) (void)hipFree(ctx->film);
     (void)hipFree(ctx->cnt);
+    (void)hipFree(ctx->gstk);
+    (void)hipFree(ctx->tmp_hid);
     (void)hipHostFree(ctx->h_cnt);
     (void)hipFree(ctx->slab);
     for (auto ev : ctx->events) (void)hipEventDestroy(ev);
@@ -544,6 +567,10 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
     case PT_OPT_EXTEND_MODE:
         if (value != 1 && value != 2) return fail(ctx, PT_ERR_ARG, "extend mode %llu unknown", (unsigned long long)value);
         ctx->extend_mode = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_LDS_SLOTS:
+        if (value < 2 || value > 64) return fail(ctx, PT_ERR_ARG, "LDS stack slots %llu out of [2, 64]", (unsigned long long)value);
+        ctx->lds_slots = (int)value;
         return PT_OK;
     case PT_OPT_TUNE_REFILL_IDLE:
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
@@ -712,12 +739,20 @@ int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void 
     if (n > 0xFFFFFFFFull) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: more than 2^32-1 rays in one call");
     if (!d_org4 || !d_dir4 || !d_hit4 || !d_t) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: NULL buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->tmp_hid_n < n) {
+        if (ctx->tmp_hid) { (void)hipFree(ctx->tmp_hid); ctx->tmp_hid = nullptr; ctx->tmp_hid_n = 0; }
+        HIPCHK(ctx, hipMalloc(&ctx->tmp_hid, n * sizeof(uint32_t)));
+        ctx->tmp_hid_n = n;
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->cnt, 0, sizeof(Counters), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
     int rc = launch_extend(ctx, (const float4 *)d_org4, (const float4 *)d_dir4, nullptr, (uint32_t)n, (uint32_t)n,
-                           (float4 *)d_hit4, (float *)d_t);
+                           ctx->tmp_hid, (float *)d_t);
     if (rc != PT_OK) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->sc,
+                       (const float4 *)d_org4, (const float4 *)d_dir4, ctx->tmp_hid, (const float *)d_t, (uint32_t)n,
+                       (float4 *)d_hit4);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (stats) {
@@ -742,11 +777,12 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
     const uint64_t chunk = 1u << 20;
     float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
     float *d_t = nullptr;
+    uint32_t *d_id = nullptr;
     const uint64_t cap = std::min(n, chunk);
     std::vector<float4> ho(cap), hd(cap), hh(cap);
     std::vector<float> ht(cap);
     int rc = PT_OK;
-    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_t); };
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_t); (void)hipFree(d_id); };
 #define ICHK(call)                                                                                              \
     do {                                                                                                        \
         hipError_t e_ = (call);                                                                                 \
@@ -759,6 +795,7 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
     ICHK(hipMalloc(&d_d, cap * sizeof(float4)));
     ICHK(hipMalloc(&d_h, cap * sizeof(float4)));
     ICHK(hipMalloc(&d_t, cap * sizeof(float)));
+    ICHK(hipMalloc(&d_id, cap * sizeof(uint32_t)));
     for (uint64_t base = 0; base < n; base += chunk) {
         const uint64_t m = std::min(chunk, n - base);
         for (uint64_t i = 0; i < m; i++) {
@@ -768,8 +805,10 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
         }
         ICHK(hipMemcpyAsync(d_o, ho.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
         ICHK(hipMemcpyAsync(d_d, hd.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        rc = launch_extend(ctx, d_o, d_d, nullptr, (uint32_t)m, (uint32_t)m, d_h, d_t);
+        rc = launch_extend(ctx, d_o, d_d, nullptr, (uint32_t)m, (uint32_t)m, d_id, d_t);
         if (rc != PT_OK) { cleanup(); return rc; }
+        hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, m)), dim3(kBlock), 0, ctx->stream, ctx->sc, d_o, d_d, d_id, d_t,
+                           (uint32_t)m, d_h);
         ICHK(hipMemcpyAsync(hh.data(), d_h, m * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
         ICHK(hipMemcpyAsync(ht.data(), d_t, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         ICHK(hipStreamSynchronize(ctx->stream));
@@ -927,7 +966,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 }
                 HIPCHK(ctx, hipEventRecord(ctx->events[ev_used], st));
             }
-            rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hit, B.t);
+            rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hid, B.t);
             if (rc != PT_OK) return rc;
             if (ctx->time_extend) {
                 HIPCHK(ctx, hipEventRecord(ctx->events[ev_used + 1], st));

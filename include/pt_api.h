@@ -115,10 +115,10 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_POOL_SIZE        1   /* path slots in flight; the reference fixes 0x200000 (src/render.cuh:14) */
 #define PT_OPT_COUNT_TRAVERSAL  2   /* 1: extend counts nodes/triangles/leaves (slower; for roofline bookkeeping) */
 #define PT_OPT_TIME_EXTEND      3   /* 1 (default): bracket every extend launch with HIP events */
-#define PT_OPT_EXTEND_MODE      5   /* 2 (default): single-loop persistent waves that refill finished ray slots;
-                                       0: loop-per-phase persistent waves; 1: plain 64-ray batches */
+#define PT_OPT_EXTEND_MODE      5   /* 2 (default): persistent waves, one traversal step per lane and iteration, finished ray
+                                       slots refilled; 1: one 64-ray batch per wave step, loop-per-phase traversal */
 #define PT_OPT_TUNE_REFILL_IDLE 6   /* extend tuning: refill a wave's ray slots once this many lanes are empty */
-#define PT_OPT_TUNE_TRI_LANES   7   /* extend tuning (mode 3): triangle steps once this many lanes wait at a leaf */
+#define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 20) */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 
