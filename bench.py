@@ -170,11 +170,17 @@ def main():
                                                 "leaves": round(ost.leaves / ost.rays, 3),
                                                 "bytes_per_ray": round(b_ray, 1)}
         out["cpu_baseline"] = cpu
+        # HBM-side bytes per extend launch, from committed rocprofv3 --pmc passes of this same command (not collected here:
+        # counter collection needs its own profiler runs); null when the summary is absent or is for another workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r1_extend_traffic.json")
+        if os.path.exists(tpath) and args.scene == "dragon" and (args.width, args.height, args.spp) == (1920, 1080, 512):
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         if b_ray is not None and acc["ms_extend"] > 0:
             achieved = b_ray * acc["rays"] / (acc["ms_extend"] * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_extend",
                 "avg_launch_ms": round(acc["ms_extend"] / max(1, acc["launches"]), 4),
                 "launches": int(acc["launches"]),

@@ -118,7 +118,7 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_EXTEND_MODE      5   /* 2 (default): persistent waves, one traversal step per lane and iteration, finished ray
                                        slots refilled; 1: one 64-ray batch per wave step, loop-per-phase traversal */
 #define PT_OPT_TUNE_REFILL_IDLE 6   /* extend tuning: refill a wave's ray slots once this many lanes are empty */
-#define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 20) */
+#define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 26) */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 
