@@ -106,11 +106,12 @@ def film_metrics(a, b):
 # Film tolerance against the oracle at equal spp and equal seed.  Both sides draw the same random numbers, so a pixel
 # differs only through ulp-level differences between the device's and libm's sin/cos/atan2/acos/pow and the order of
 # the float atomics (about 1e-5 relative), except where such a difference flips a discrete decision of one path (a
-# silhouette hit, a Russian-roulette or lobe choice) and that path's whole contribution changes.  Measured on MI355X:
-# 0.05 % of the pixels at 1 spp.  Stated bar: at most 1 % of the pixels differ by more than 1e-3 relative, and the
-# relMSE against the oracle is below 5 % of the Monte-Carlo noise floor (relMSE between two oracle renders that differ
-# only in seed).
-MAX_DIFFERING_PIXELS = 0.01
+# silhouette hit on a sub-pixel triangle, a Russian-roulette or lobe choice) and that path's whole contribution changes.
+# Measured on MI355X: about 0.07 % of the paths (0.54 % of the pixels at 8 spp, 0.17 % at 2 spp).  Stated bar: the
+# share of pixels differing by more than 1e-3 relative is at most 0.2 % per sample per pixel, and the relMSE against
+# the oracle is below 5 % of the Monte-Carlo noise floor (relMSE between two oracle renders that differ only in seed;
+# measured ratios 0.0003 .. 0.01).
+MAX_FLIPPED_PATH_RATE = 0.002
 MAX_RELMSE_OVER_NOISE = 0.05
 
 
@@ -128,7 +129,7 @@ def test_render_matches_oracle(pkg, ctx, name):
     rel_mse, differing = film_metrics(film, ofilm)
     ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
     floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_DIFFERING_PIXELS, "%.4f of the pixels differ" % differing
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
     assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
     # tone-mapped 16-bit images: RMSE below a quarter of the seed-to-seed RMSE at this sample count
     tm = lambda f: pkg.tonemap16(f).astype(np.float64) / 65535
@@ -303,4 +304,4 @@ def test_full_size_frame_properties(pkg, ctx):
     rel_mse, differing = film_metrics(full, ofilm)
     ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2, nthreads=16)
     floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_DIFFERING_PIXELS and rel_mse <= MAX_RELMSE_OVER_NOISE * floor, (differing, rel_mse, floor)
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp and rel_mse <= MAX_RELMSE_OVER_NOISE * floor, (differing, rel_mse, floor)
