@@ -34,7 +34,7 @@ using namespace ptd;
 
 namespace {
 
-constexpr uint32_t kDefaultPool = 1u << 22;
+constexpr uint32_t kDefaultPool = 1u << 27;   // upper bound; a render uses no more slots than it has paths
 
 struct PathBuf {
     float4 *o;      // origin xyz
@@ -405,11 +405,12 @@ static void free_pool(pt_ctx *ctx)
     ctx->pool_alloc = 0;
 }
 
-static int ensure_pool(pt_ctx *ctx)
+// Grow-only: the buffers hold at least `slots` paths afterwards.
+static int ensure_pool(pt_ctx *ctx, uint32_t slots)
 {
-    if (ctx->pool_alloc == ctx->pool) return PT_OK;
+    if (ctx->pool_alloc >= slots) return PT_OK;
     free_pool(ctx);
-    const size_t P = ctx->pool;
+    const size_t P = slots;
     for (auto &b : ctx->buf) {
         HIPCHK(ctx, hipMalloc(&b.o, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.d, P * sizeof(float4)));
@@ -418,7 +419,7 @@ static int ensure_pool(pt_ctx *ctx)
         HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
     }
     HIPCHK(ctx, hipMalloc(&ctx->queues, 4 * P * sizeof(uint32_t)));
-    ctx->pool_alloc = ctx->pool;
+    ctx->pool_alloc = slots;
     return PT_OK;
 }
 
@@ -910,10 +911,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         return fail(ctx, PT_ERR_ARG, "pt_render: sample range [%llu,+%llu) of %llu not supported",
                     (unsigned long long)spp_begin, (unsigned long long)spp_count, (unsigned long long)spp_total);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_pool(ctx);
-    if (rc != PT_OK) return rc;
-
-    const uint32_t P = ctx->pool, W = ctx->W, H = ctx->H;
+    const uint32_t W = ctx->W, H = ctx->H;
     const uint32_t npix = W * H;
     const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
     hipStream_t st = ctx->stream;
@@ -927,6 +925,12 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         HIPCHK(ctx, hipMalloc(&ctx->slab, slab_samples * per_sample));
         ctx->slab_bytes = slab_samples * per_sample;
     }
+
+    // path pool: the configured size, but no more slots than a slab has paths (rounded up to whole refill spans)
+    const uint64_t slab_paths = ((uint64_t)npix * slab_samples + 65535) & ~65535ull;
+    const uint32_t P = (uint32_t)std::min<uint64_t>(ctx->pool, slab_paths);
+    int rc = ensure_pool(ctx, P);
+    if (rc != PT_OK) return rc;
 
     pt_stats acc{};
     size_t ev_used = 0;
