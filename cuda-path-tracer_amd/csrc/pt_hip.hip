@@ -46,8 +46,8 @@ struct PathBuf {
 
 struct Counters {
     uint32_t n_in;                  // rays in the current buffer
-    uint32_t q_count[4];            // material queue lengths (diffuse, glossy, mirror, glass)
-    uint32_t pad[3];
+    uint32_t n_out;                 // rays the bounce kernel has appended to the other buffer so far
+    uint32_t pad[6];
     unsigned long long next_sample; // next global sample index to hand out
     unsigned long long total_samples;
     unsigned long long rays_total;
@@ -62,9 +62,6 @@ __device__ __forceinline__ int mat_slot(uint32_t type)
     return type == PT_DIFFUSE ? 0 : (type == PT_GLOSSY ? 1 : (type == PT_MIRROR ? 2 : (type == PT_GLASS ? 3 : 0)));
 }
 
-// --------------------------------------------------------------------------------------------------------------
-// logic: reference src/render.cu:49-89
-// --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t material_type_of(const DScene &sc, uint32_t prim)
 {
     if (prim & PT_PRIM_PLANE) return sc.planes[prim & 0x3FFFFFFFu].type;
@@ -78,145 +75,144 @@ __device__ __forceinline__ float4 material_of(const DScene &sc, uint32_t prim)
     return sc.mesh_mat;
 }
 
-constexpr int kLogicBatches = 8;     // 64-ray batches a wave settles before it touches the queue counters
-
-__global__ __launch_bounds__(kBlock) void k_logic(DScene sc, PathBuf A, Counters *cnt, uint32_t *__restrict__ queues,
-                                                  uint32_t P, float4 *__restrict__ slab, uint32_t slab_first_sample,
-                                                  uint32_t npix, float spp_total, uint32_t seed0, uint32_t seed1)
+// What a path adds to its pixel if its current ray leaves the scene or is cut at the depth limit: throughput times the
+// environment in the ray's direction over the sample count (reference src/render.cu:62-72).  Every kernel that creates
+// a ray stores this value in the path's slab entry right away; a later bounce of the same path overwrites it, so the
+// entry holds the right value whenever the path ends, and ending a path costs no environment lookup.
+__device__ __forceinline__ float4 escape_value(float4 th, float4 e, float spp_total)
 {
-    const uint32_t n = cnt->n_in;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
-    constexpr uint32_t kSpan = kLogicBatches * 64;
-    // Each wave owns spans of kLogicBatches * 64 consecutive rays.  It decides every ray of a span first, then claims
-    // queue space with ONE atomic per material for the whole span: all waves add to the same four counters, and
-    // same-address atomics are what this kernel would otherwise wait for.
-    for (uint32_t span = wave; (uint64_t)span * kSpan < n; span += nwaves) {
-        int slots[kLogicBatches];
-        uint32_t total[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < kLogicBatches; b++) {
-            const uint32_t i = span * kSpan + b * 64 + lane;
-            int slot = -1;
-            if (i < n) {
-                const float t = A.t[i];
-                const float4 d4 = A.d[i];
-                float4 th = A.thr[i];
-                const uint32_t pixel = __float_as_uint(d4.w);
-                const uint32_t sk = __float_as_uint(th.w);
-                const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-                if (t == kFltMax || 2 * k >= kMaxDepth) {
-                    // miss or depth limit: the path contributes throughput * env(direction) / spp (src/render.cu:62-72)
-                    const float4 e = env_lookup(sc, xyz(d4));
-                    slab[(size_t)(sample - slab_first_sample) * npix + pixel] =
-                        make_float4(th.x * e.x / spp_total, th.y * e.y / spp_total, th.z * e.z / spp_total, 0.0f);
-                } else {
-                    bool alive = true;
-                    if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
-                        Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
-                        const float p = fmaxf(th.x, fmaxf(th.y, th.z));
-                        if (rng.next() > p) {
-                            alive = false;
-                            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        } else {
-                            const float ip = 1 / p;
-                            th.x *= ip; th.y *= ip; th.z *= ip;
-                            A.thr[i] = th;
-                        }
-                    }
-                    if (alive) slot = mat_slot(material_type_of(sc, A.hid[i]));
-                }
-            }
-            slots[b] = slot;
-#pragma unroll
-            for (int m = 0; m < 4; m++) total[m] += (uint32_t)__popcll(__ballot(slot == m));
-        }
-        // wave-aggregated queue append: one atomic per material, wave and span
-        uint32_t base[4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            uint32_t pos = 0;
-            if (total[m] != 0 && lane == 0) pos = atomicAdd(&cnt->q_count[m], total[m]);
-            base[m] = __shfl(pos, 0);
-        }
-#pragma unroll
-        for (int b = 0; b < kLogicBatches; b++) {
-            const uint32_t i = span * kSpan + b * 64 + lane;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const bool mine = slots[b] == m;
-                const unsigned long long mask = __ballot(mine);
-                const uint32_t prefix =
-                    __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-                if (mine) queues[(size_t)m * P + base[m] + prefix] = i;
-                base[m] += (uint32_t)__popcll(mask);
-            }
-        }
-    }
+    return make_float4(th.x * e.x / spp_total, th.y * e.y / spp_total, th.z * e.z / spp_total, 0.0f);
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// shade: reference src/render.cu:129-242, one kernel per material queue
+// shade: reference src/render.cu:129-242.  One material per instantiation; returns the new direction and scales the
+// throughput.  env_out = environment texel in the new direction (the Lambertian pdf needs it, the caller stores the
+// path's escape value from it).
 // --------------------------------------------------------------------------------------------------------------
 template <int MAT>
-__global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PathBuf A, PathBuf B, const Counters *cnt,
-                                                  const uint32_t *__restrict__ queues, uint32_t P, uint32_t seed0,
-                                                  uint32_t seed1)
+__device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 mat, Rng &rng, float4 &th, float4 &env_out)
 {
-    const uint32_t n = cnt->q_count[MAT];
-    uint32_t off = 0;
+    f3 out;
+    bool lambert = false;
+    if (MAT == 2) {                                     // mirror (src/render.cu:195-211)
+        out = reflect3(d, n3);
+        th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
+    } else if (MAT == 3) {                              // glass (src/render.cu:213-242)
+        const bool external = dot3(d, n3) < 0;
+        const f3 nn = external ? n3 : -n3;
+        const float ref_idx = external ? (1 / mat.w) : mat.w;
+        const float cos_t = fminf(dot3(-d, nn), 1.0f);
+        const float sin_t = sqrtf(__fmaf_rn(-cos_t, cos_t, 1.0f));
+        if (ref_idx * sin_t > 1.0f || schlick(cos_t, ref_idx) > rng.next()) out = reflect3(d, nn);
+        else out = refract_dir(d, nn, ref_idx);
+        th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
+    } else if (MAT == 1) {                              // glossy (src/render.cu:164-193)
+        if (rng.next() < 0.05f) out = reflect3(d, n3);  // throughput untouched
+        else lambert = true;
+    } else {
+        lambert = true;                                 // Lambertian (src/render.cu:129-162)
+    }
+    if (lambert) out = (rng.next() < 0.5f) ? diffuse_dir(n3, rng) : env_sample_lights(sc, rng);
+    env_out = env_lookup(sc, out);
+    if (lambert) {
+        const float env_pdf = env_out.w;
+        const float diff_pdf = fmaxf(dot3(n3, out) / kPi, 0.0f);
+        const float mixed_pdf = (env_pdf + diff_pdf) * 0.5f;
+        const float s = diff_pdf / mixed_pdf;
+        th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
+    }
+    return out;
+}
+
+// --------------------------------------------------------------------------------------------------------------
+// bounce = logic (reference src/render.cu:49-89) + shade of the surviving paths, in one pass over the ray buffer.
+//
+// The reference sorts surviving paths into one queue per material and shades each queue with its own kernel.  Here a
+// path is decided and shaded by the same thread: the four material branches are short next to the memory traffic, and
+// shading from queues meant reading every survivor's state a second time through an index (sparse 16 B reads that
+// fetched four times the bytes they used).  Survivors are appended to the other buffer in input order; a block of
+// kBounceBlock threads claims its output range with ONE atomic, because every block adds to the same counter and
+// same-address atomics are what this kernel would otherwise wait for.
+// --------------------------------------------------------------------------------------------------------------
+constexpr int kBounceBlock = 512;
+constexpr int kBounceWaves = kBounceBlock / 64;
+
+__global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
+                                                         float4 *__restrict__ slab, uint32_t slab_first_sample,
+                                                         uint32_t npix, float spp_total, uint32_t seed0, uint32_t seed1)
+{
+    __shared__ uint32_t s_wave[2][kBounceWaves];
+    __shared__ uint32_t s_base[2];
+    const uint32_t n = cnt->n_in;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int par = 0;
+    // the trip count is the same for every thread of a block (barriers inside)
+    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += gridDim.x * kBounceBlock, par ^= 1) {
+        const uint32_t i = first + threadIdx.x;
+        bool alive = false;
+        float4 th = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 0, 0);
+        float t = 0;
+        uint32_t pixel = 0, sample = 0, k = 0;
+        if (i < n) {
+            t = A.t[i];
+            th = A.thr[i];
+            const uint32_t sk = __float_as_uint(th.w);
+            sample = sk & 0x07FFFFFFu;
+            k = sk >> 27;
+            // a miss or the depth limit ends the path with the escape value its slab entry already holds
+            if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
+                alive = true;
+                d4 = A.d[i];
+                pixel = __float_as_uint(d4.w);
+                if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+                    Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+                    const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+                    if (rng.next() > p) {
+                        alive = false;
+                        slab[(size_t)(sample - slab_first_sample) * npix + pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else {
+                        const float ip = 1 / p;
+                        th.x *= ip; th.y *= ip; th.z *= ip;
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(alive);
+        if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
 #pragma unroll
-    for (int m = 0; m < MAT; m++) off += cnt->q_count[m];
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
-        const uint32_t i = queues[(size_t)MAT * P + j];
-        const float4 o4 = A.o[i], d4 = A.d[i];
-        const uint32_t hid = A.hid[i];
-        float4 th = A.thr[i];
-        const float t = A.t[i];
-        const uint32_t pixel = __float_as_uint(d4.w);
-        const uint32_t sk = __float_as_uint(th.w);
-        const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-        const float4 mat = material_of(sc, hid);
-        const f3 o = xyz(o4), d = xyz(d4);
-        uint32_t prim;
-        const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
-        const f3 hitp = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
-        Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
-        f3 out;
-        bool lambert = false;
-        if (MAT == 2) {                                     // mirror (src/render.cu:195-211)
-            out = reflect3(d, n3);
-            th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
-        } else if (MAT == 3) {                              // glass (src/render.cu:213-242)
-            const bool external = dot3(d, n3) < 0;
-            const f3 nn = external ? n3 : -n3;
-            const float ref_idx = external ? (1 / mat.w) : mat.w;
-            const float cos_t = fminf(dot3(-d, nn), 1.0f);
-            const float sin_t = sqrtf(__fmaf_rn(-cos_t, cos_t, 1.0f));
-            if (ref_idx * sin_t > 1.0f || schlick(cos_t, ref_idx) > rng.next()) out = reflect3(d, nn);
-            else out = refract_dir(d, nn, ref_idx);
-            th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
-        } else if (MAT == 1) {                              // glossy (src/render.cu:164-193)
-            if (rng.next() < 0.05f) out = reflect3(d, n3);  // throughput untouched
-            else lambert = true;
-        } else {
-            lambert = true;                                 // Lambertian (src/render.cu:129-162)
+            for (int w = 0; w < kBounceWaves; w++) total += s_wave[par][w];
+            s_base[par] = total ? atomicAdd(&cnt->n_out, total) : 0u;
         }
-        if (lambert) {
-            out = (rng.next() < 0.5f) ? diffuse_dir(n3, rng) : env_sample_lights(sc, rng);
-            const float env_pdf = env_lookup(sc, out).w;
-            const float diff_pdf = fmaxf(dot3(n3, out) / kPi, 0.0f);
-            const float mixed_pdf = (env_pdf + diff_pdf) * 0.5f;
-            const float s = diff_pdf / mixed_pdf;
-            th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
+        __syncthreads();
+        uint32_t dst = s_base[par];
+#pragma unroll
+        for (int w = 0; w < kBounceWaves; w++) dst += (uint32_t)w < wave ? s_wave[par][w] : 0u;
+        dst += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (alive) {
+            const float4 o4 = A.o[i];
+            const uint32_t hid = A.hid[i];
+            const float4 mat = material_of(sc, hid);
+            const int slot = mat_slot(material_type_of(sc, hid));
+            const f3 o = xyz(o4), d = xyz(d4);
+            uint32_t prim;
+            const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
+            const f3 hitp = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
+            Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
+            f3 out;
+            float4 e;
+            if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
+            else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
+            else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
+            else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
+            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e, spp_total);
+            th.w = __uint_as_float(sample | ((k + 1) << 27));
+            B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
+            B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
+            B.thr[dst] = th;
         }
-        th.w = __uint_as_float(sample | ((k + 1) << 27));
-        const uint32_t dst = off + j;
-        B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
-        B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
-        B.thr[dst] = th;
     }
 }
 
@@ -225,14 +221,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(DScene sc, PathBuf A, PathBuf 
 // --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void new_take(const Counters *cnt, uint32_t P, uint32_t &n_out, uint32_t &take)
 {
-    n_out = cnt->q_count[0] + cnt->q_count[1] + cnt->q_count[2] + cnt->q_count[3];
+    n_out = cnt->n_out;
     const unsigned long long remaining = cnt->total_samples - cnt->next_sample;
     const unsigned long long room = P - n_out;
     take = (uint32_t)(remaining < room ? remaining : room);
 }
 
 __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const Counters *cnt, uint32_t P, uint32_t W,
-                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1)
+                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
+                                                     float4 *__restrict__ slab, float spp_total)
 {
     uint32_t n_out, take;
     new_take(cnt, P, n_out, take);
@@ -251,9 +248,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const
         f3 o, d;
         camera_ray(sc.cam, W, H, x, y, rng, o, d);
         const uint32_t dst = n_out + j;
+        const float4 th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+        slab[(size_t)s_local * npix + pixel] = escape_value(th, env_lookup(sc, d), spp_total);
         B.o[dst] = make_float4(o.x, o.y, o.z, 0.0f);
         B.d[dst] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
-        B.thr[dst] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+        B.thr[dst] = th;
     }
 }
 
@@ -269,7 +268,7 @@ __global__ void k_advance(Counters *cnt, uint32_t P)
     cnt->rays_total += n_in;
     cnt->iter += 1;
     if (n_in) cnt->extend_nonempty += 1;
-    cnt->q_count[0] = cnt->q_count[1] = cnt->q_count[2] = cnt->q_count[3] = 0;
+    cnt->n_out = 0;
 }
 
 // Sums a pixel's slab entries in sample order and adds the sum to the film (float3 per pixel, row 0 = top).
@@ -358,7 +357,6 @@ struct pt_ctx {
     // wavefront state
     uint32_t pool_alloc = 0;
     PathBuf buf[2]{};
-    uint32_t *queues = nullptr;
     Counters *cnt = nullptr;
     Counters *h_cnt = nullptr;     // pinned, 4 slots
     std::vector<hipEvent_t> events;
@@ -400,8 +398,6 @@ static void free_pool(pt_ctx *ctx)
         (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hid); (void)hipFree(b.t);
         b = PathBuf{};
     }
-    (void)hipFree(ctx->queues);
-    ctx->queues = nullptr;
     ctx->pool_alloc = 0;
 }
 
@@ -418,7 +414,6 @@ static int ensure_pool(pt_ctx *ctx, uint32_t slots)
         HIPCHK(ctx, hipMalloc(&b.hid, P * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
     }
-    HIPCHK(ctx, hipMalloc(&ctx->queues, 4 * P * sizeof(uint32_t)));
     ctx->pool_alloc = slots;
     return PT_OK;
 }
@@ -936,6 +931,8 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
     size_t ev_used = 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
     const int gs = stream_grid(ctx, P);
+    const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
+                                                                 ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
 
     for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
         const uint64_t first = spp_begin + done_samples;
@@ -953,16 +950,11 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         int cur = 0;       // buffer holding the extended rays
         while (!done) {
             PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
-            if (it > 0) {
-                hipLaunchKernelGGL(k_logic, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, ctx->cnt, ctx->queues, P, ctx->slab,
+            if (it > 0)
+                hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab,
                                    (uint32_t)first, npix, (float)spp_total, s0, s1);
-                hipLaunchKernelGGL(k_shade<0>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-                hipLaunchKernelGGL(k_shade<1>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-                hipLaunchKernelGGL(k_shade<2>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-                hipLaunchKernelGGL(k_shade<3>, dim3(gs), dim3(kBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->queues, P, s0, s1);
-            }
             hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
-                               s1);
+                               s1, ctx->slab, (float)spp_total);
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
             if (ctx->time_extend) {
                 while (ctx->events.size() < ev_used + 2) {

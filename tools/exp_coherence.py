@@ -10,7 +10,8 @@ scene = pkg.HostScene(S.scene_file(pkg, "dragon"), W, H)
 ctx = pkg.Context(0); ctx.upload(scene)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 ctx.set_option(pkg.OPT_EXTEND_MODE, mode)
-org, dir_ = ctx.primary_rays(W, H, sample=0, seed=1)
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+parts = [ctx.primary_rays(W, H, sample=s_, seed=1) for s_ in range(NS)]
 # put rays in the generate stage's tile order: 8x4 tiles
 ys, xs = np.divmod(np.arange(W * H), W)
 def tile_order():
@@ -19,6 +20,7 @@ def tile_order():
     x = tx * 8 + (inn & 7); y = ty * 4 + (inn >> 3)
     return (H - y - 1) * W + x
 perm = tile_order()
+org = np.concatenate([p_[0][perm] for p_ in parts]); dir_ = np.concatenate([p_[1][perm] for p_ in parts])
 def run(o, d, label):
     n = o.shape[0]
     o4 = torch.zeros((n, 4)); d4 = torch.zeros((n, 4)); o4[:, :3] = torch.from_numpy(o); d4[:, :3] = torch.from_numpy(d)
@@ -30,10 +32,10 @@ def run(o, d, label):
         best = min(best, st.ms_total)
     print("%-40s n=%8d  %7.3f ms  %8.1f Mrays/s  hit %.2f" % (label, n, best, n / best / 1e3, float((t < 1e38).float().mean())))
     return hit.cpu().numpy(), t.cpu().numpy()
-o_t, d_t = org[perm], dir_[perm]
+o_t, d_t = org, dir_
 hit, t = run(o_t, d_t, "primary, tile order")
 rng = np.random.default_rng(0)
-sh = rng.permutation(W * H)
+sh = rng.permutation(org.shape[0])
 run(org[sh], dir_[sh], "primary, shuffled")
 # secondary rays: cosine-ish around the normal at the hit
 nrm = hit[:, :3]; m = t < 1e38
