@@ -16,6 +16,7 @@ DIFFUSE, MIRROR, GLOSSY, GLASS = 0x4, 0x8, 0x10, 0x20
 PRIM_MISS, PRIM_PLANE, PRIM_SPHERE = 0xFFFFFFFF, 0x80000000, 0x40000000
 OPT_POOL_SIZE, OPT_COUNT_TRAVERSAL, OPT_TIME_EXTEND, OPT_SLAB_BYTES, OPT_EXTEND_MODE = 1, 2, 3, 4, 5
 OPT_TUNE_REFILL_IDLE, OPT_TUNE_LDS_SLOTS = 6, 7
+OPT_ENV_PACK = 8
 
 
 class Plane(C.Structure):
@@ -133,6 +134,7 @@ def hip_lib():
         L.pt_film_clear.argtypes = [C.c_void_p]
         L.pt_film_download.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
+        L.pt_env_is_packed.argtypes = [C.c_void_p]
         L.pt_stream.restype = C.c_void_p
         L.pt_stream.argtypes = [C.c_void_p]
         _hip = L
@@ -358,6 +360,14 @@ class Context:
     @property
     def stream(self):
         return self._L.pt_stream(self._h)
+
+    @property
+    def env_is_packed(self):
+        """True when the uploaded scene keeps its environment texels in the packed 8-byte form."""
+        rc = self._L.pt_env_is_packed(self._h)
+        if rc < 0:
+            raise PtError("no scene uploaded")
+        return rc == 1
 
 
 def spp_partition(spp_total, world_size, rank):

@@ -62,7 +62,12 @@ struct DScene {
     const DSphere *spheres;
     uint32_t num_planes, num_spheres, has_bvh, mesh_type;
     float4 mesh_mat;
-    const float4 *env;       // [envH][envW] rgb + pdf
+    const float4 *env;       // [envH][envW] rgb + pdf, or NULL when envp is used
+    // Packed form of the same texels: rgb as one shared-exponent word (exact: chosen only when every texel of the map
+    // is a value such a word can hold, as maps decoded from Radiance .hdr files are) + the pdf, 8 B per texel in 4x4
+    // tiles of 128 B.  The 2x2 footprint of a bilinear fetch then touches 1.6 lines on average instead of 2.25.
+    const uint2 *envp;
+    uint32_t env_tiles_x;    // tiles per tile row
     const uint16_t *marg;    // [envW]
     const uint16_t *cond;    // [envW*envH]
     uint32_t envW, envH;
@@ -201,6 +206,18 @@ __device__ __forceinline__ void hit_triangle(float4 v00, float4 v11, float4 v22,
 // ---- environment map --------------------------------------------------------------------------------------------
 __device__ __forceinline__ float clamp1(float x) { return x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x); }
 
+__device__ __forceinline__ float4 env_texel(const DScene &sc, int x, int y)
+{
+    if (sc.envp) {
+        const uint2 v = sc.envp[((size_t)(y >> 2) * sc.env_tiles_x + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)];
+        // mantissa * 2^(E - 136); the all-zero word is black
+        const float scale = v.x ? __uint_as_float(((v.x >> 24) - 9u) << 23) : 0.0f;
+        return make_float4((float)(v.x & 255u) * scale, (float)((v.x >> 8) & 255u) * scale,
+                           (float)((v.x >> 16) & 255u) * scale, __uint_as_float(v.y));
+    }
+    return sc.env[(size_t)y * sc.envW + x];
+}
+
 // fp32 bilinear fetch with wrap addressing at normalised coordinates (reference src/environment_map.cu:156-162)
 __device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float theta)
 {
@@ -212,8 +229,8 @@ __device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float t
     int ix = (int)fx0, iy = (int)fy0;
     int x0 = ((ix % W) + W) % W, x1 = (x0 + 1) % W;
     int y0 = ((iy % H) + H) % H, y1 = (y0 + 1) % H;
-    float4 t00 = sc.env[(size_t)y0 * W + x0], t10 = sc.env[(size_t)y0 * W + x1];
-    float4 t01 = sc.env[(size_t)y1 * W + x0], t11 = sc.env[(size_t)y1 * W + x1];
+    const float4 t00 = env_texel(sc, x0, y0), t10 = env_texel(sc, x1, y0);
+    const float4 t01 = env_texel(sc, x0, y1), t11 = env_texel(sc, x1, y1);
     float4 r;
 #define PT_BILERP(c) { float top = __fmaf_rn(fx, t10.c - t00.c, t00.c); float bot = __fmaf_rn(fx, t11.c - t01.c, t01.c); \
                        r.c = __fmaf_rn(fy, bot - top, top); }

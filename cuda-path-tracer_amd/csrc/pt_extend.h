@@ -22,7 +22,10 @@ namespace ptd {
 constexpr int kBlock = 256;
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 constexpr uint32_t kChunk = 128;           // rays per chunk; chunk c belongs to wave c mod #waves
-constexpr int kRefillIdle = 24;            // stream kernel: refill once this many lanes have no ray
+// stream kernel: refill once this many lanes have no ray.  Measured on the 868 k-triangle stand-in, 78 M rays per launch
+// (ms per frame): 8 -> 356, 16 -> 342, 24 -> 333, 32 -> 327, 44 -> 320, 56 -> 340.  Idle lanes cost no memory traffic,
+// which is what bounds the kernel; every refill is issue time the wave's live rays stand still for.
+constexpr int kRefillIdle = 44;
 
 struct ExtendArgs {
     const float4 *ro;          // ray origins (xyz)
@@ -271,39 +274,56 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     uint32_t ray = kNoRay;
     bool degenerate = false;
     bool canon = false;          // wave-uniform: some ray in flight needs the NaN-rewriting slab test
-    bool more_work = true;
+
+    // Every lane keeps the NEXT ray it will trace already loaded (origin and direction in registers), so that starting
+    // a ray costs no memory round trip during which the wave's other rays would stand still: the loads are issued when
+    // the previous ray starts and have long arrived when it ends.
+    uint32_t pray = kNoRay;
+    float4 po = make_float4(0, 0, 0, 0), pd = po;
+    auto fetch_ahead = [&]() {
+        bool want = pray == kNoRay;
+        unsigned long long m = __ballot(want);
+        while (m) {
+            if (next >= end) {
+                const uint64_t c2 = (uint64_t)chunk + nwaves;
+                if (c2 * kChunk >= n) break;
+                chunk = (uint32_t)c2;
+                next = chunk * kChunk;
+                end = min(n, next + kChunk);
+            }
+            const uint32_t take = min(end - next, (uint32_t)__popcll(m));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (want && rank < take) {
+                pray = next + rank;
+                po = a.ro[pray];
+                pd = a.rd[pray];
+                want = false;
+            }
+            next += take;
+            m = __ballot(want);
+        }
+    };
+    fetch_ahead();
 
     for (;;) {
-        const int nidle = __popcll(__ballot(R.node == kSentinel));
-        if (nidle == 64 || (more_work && nidle >= a.refill_idle)) {
-            // retire finished rays, refill their slots
-            if (ray != kNoRay && R.node == kSentinel) {
+        const bool idle = R.node == kSentinel;
+        const int nidle = __popcll(__ballot(idle));
+        if (nidle == 64 || (nidle >= a.refill_idle && __any(idle && pray != kNoRay))) {
+            // retire finished rays, start the rays fetched ahead, fetch the ones after them
+            if (ray != kNoRay && idle) {
                 ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
             }
-            const bool empty = ray == kNoRay;
-            const unsigned long long emask = __ballot(empty);
-            if (next >= end) {
-                const uint64_t c2 = (uint64_t)chunk + nwaves;
-                if (c2 * kChunk < n) {
-                    chunk = (uint32_t)c2;
-                    next = chunk * kChunk;
-                    end = min(n, next + kChunk);
-                }
-            }
-            const uint32_t take = min(end - next, (uint32_t)__popcll(emask));
-            const uint32_t rank =
-                __builtin_amdgcn_mbcnt_hi((uint32_t)(emask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emask, 0));
-            if (empty && rank < take) {
-                ray = next + rank;
-                ray_begin(sc, R, xyz(a.ro[ray]), xyz(a.rd[ray]), stk);
+            if (ray == kNoRay && pray != kNoRay) {
+                ray = pray;
+                pray = kNoRay;
+                ray_begin(sc, R, xyz(po), xyz(pd), stk);
                 degenerate = slab_degenerate(R.d);
             }
-            next += take;
-            more_work = next < end || ((uint64_t)chunk + nwaves) * kChunk < n;
+            fetch_ahead();
             canon = __any(degenerate);
-            if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
+            if (!__any(ray != kNoRay)) break;            // nothing in flight, so nothing fetched ahead either
         }
         if (canon) stream_step<COUNT, true>(sc, R, stk);
         else stream_step<COUNT, false>(sc, R, stk);

@@ -1,25 +1,27 @@
 // libpt_hip.so: wavefront path tracing on MI355X (gfx950) behind the C ABI of include/pt_api.h.
 //
 // One wavefront iteration advances every live path by one segment:
-//   logic    (terminate on miss / depth limit, Russian roulette, sort survivors into 4 material queues with one
-//             wave-aggregated atomic per material and wave)
-//   shade x4 (one kernel per material reads its queue and writes the continued ray, compacted, into the other
-//             path buffer)
+//   bounce   (logic + shade: ends paths on miss / depth limit / Russian roulette, shades the survivors whatever their
+//             material and appends their continued rays, in input order, to the other path buffer; one atomic per
+//             512-thread block)
 //   generate (fills the rest of that buffer with new camera paths)
 //   advance  (one thread: rolls the device-side counters over)
 //   extend   (closest hit for every ray of the new buffer)
-// Path state ping-pongs between two SoA buffers, so every state access except the queue gather is a coalesced
-// 16 B-per-lane stream.  All counters live on the device; the host only polls them (lagging) to learn when to stop.
+// Path state ping-pongs between two SoA buffers, so every state access is a coalesced 16 B-per-lane stream.  All
+// counters live on the device; the host only polls them (lagging) to learn when to stop.
 //
-// Film accumulation uses no atomics.  Every camera path ends exactly once (miss, depth limit or Russian roulette) and
-// at that point stores its contribution (zero when roulette killed it) into its own float4 of a "sample slab"
-// indexed [sample][pixel]; scattered float atomics run an order of magnitude below plain stores on this chip, and HBM
-// is large enough to hold a slab of hundreds of samples per pixel.  When a slab's samples have all ended, one
-// streaming kernel sums them per pixel in sample order and adds the sum to the film, so the film is reproducible bit
-// for bit from run to run.
+// Film accumulation uses no atomics.  A path adds to its pixel exactly once, when it ends, and what it adds then is
+// known as soon as its last ray is created (throughput x environment in that ray's direction, or zero after Russian
+// roulette).  So each path owns one float4 of a "sample slab" indexed [sample][pixel]; the kernel that creates a ray
+// stores the ray's escape value there, overwriting the previous bounce's, and ending a path needs no lookup at all.
+// Scattered float atomics run an order of magnitude below plain stores on this chip, and HBM is large enough to hold
+// a slab of hundreds of samples per pixel.  When a slab's samples have all ended, one streaming kernel sums them per
+// pixel in sample order and adds the sum to the film, so the film is reproducible bit for bit from run to run and
+// independent of pool size and kernel scheduling.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -150,58 +152,59 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
     for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += gridDim.x * kBounceBlock, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
         bool alive = false;
-        float4 th = make_float4(0, 0, 0, 0), d4 = make_float4(0, 0, 0, 0);
-        float t = 0;
-        uint32_t pixel = 0, sample = 0, k = 0;
+        float4 th = make_float4(0, 0, 0, 0), d4 = th, o4 = th;
+        float t = kFltMax;
+        uint32_t hid = PT_PRIM_MISS;
         if (i < n) {
+            // the whole state in one batch of loads: a path that ends here wastes 36 of the 56 bytes, but its neighbours
+            // in the same cache lines need them anyway and nothing below waits for a second round trip
             t = A.t[i];
             th = A.thr[i];
-            const uint32_t sk = __float_as_uint(th.w);
-            sample = sk & 0x07FFFFFFu;
-            k = sk >> 27;
-            // a miss or the depth limit ends the path with the escape value its slab entry already holds
-            if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
-                alive = true;
-                d4 = A.d[i];
-                pixel = __float_as_uint(d4.w);
-                if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
-                    Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
-                    const float p = fmaxf(th.x, fmaxf(th.y, th.z));
-                    if (rng.next() > p) {
-                        alive = false;
-                        slab[(size_t)(sample - slab_first_sample) * npix + pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    } else {
-                        const float ip = 1 / p;
-                        th.x *= ip; th.y *= ip; th.z *= ip;
-                    }
+            d4 = A.d[i];
+            o4 = A.o[i];
+            hid = A.hid[i];
+        }
+        const uint32_t sk = __float_as_uint(th.w);
+        const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+        const uint32_t pixel = __float_as_uint(d4.w);
+        // a miss or the depth limit ends the path with the escape value its slab entry already holds
+        if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
+            alive = true;
+            if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+                Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+                const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+                if (rng.next() > p) {
+                    alive = false;
+                    slab[(size_t)(sample - slab_first_sample) * npix + pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    const float ip = 1 / p;
+                    th.x *= ip; th.y *= ip; th.z *= ip;
                 }
             }
         }
         const unsigned long long mask = __ballot(alive);
         if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(mask);
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
+        uint32_t woff = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < kBounceWaves; w++) total += s_wave[par][w];
-            s_base[par] = total ? atomicAdd(&cnt->n_out, total) : 0u;
+        for (int w = 0; w < kBounceWaves; w++) {
+            const uint32_t c = s_wave[par][w];
+            woff += (uint32_t)w < wave ? c : 0u;
+            total += c;
         }
-        __syncthreads();
-        uint32_t dst = s_base[par];
-#pragma unroll
-        for (int w = 0; w < kBounceWaves; w++) dst += (uint32_t)w < wave ? s_wave[par][w] : 0u;
-        dst += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        // one thread claims the block's output range; the others shade meanwhile and meet it at the second barrier
+        uint32_t claimed = 0;
+        if (threadIdx.x == 0 && total) claimed = atomicAdd(&cnt->n_out, total);
+        const uint32_t r = woff + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        f3 out = mk3(0, 0, 0), hitp = out;
         if (alive) {
-            const float4 o4 = A.o[i];
-            const uint32_t hid = A.hid[i];
             const float4 mat = material_of(sc, hid);
             const int slot = mat_slot(material_type_of(sc, hid));
             const f3 o = xyz(o4), d = xyz(d4);
             uint32_t prim;
             const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
-            const f3 hitp = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
+            hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
-            f3 out;
             float4 e;
             if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
             else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
@@ -209,6 +212,11 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
             slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e, spp_total);
             th.w = __uint_as_float(sample | ((k + 1) << 27));
+        }
+        if (threadIdx.x == 0) s_base[par] = claimed;
+        __syncthreads();
+        if (alive) {
+            const uint32_t dst = s_base[par] + r;
             B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
             B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
             B.thr[dst] = th;
@@ -339,6 +347,7 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
+    bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
@@ -424,6 +433,34 @@ static void free_scene(pt_ctx *ctx)
     ctx->scene_allocs.clear();
     ctx->have_scene = false;
     ctx->sc = DScene{};
+}
+
+// rgb -> one word (three 8-bit mantissas, one exponent E, value = mantissa * 2^(E - 136)) if that is exact.
+static bool pack_shared_exponent(float4 c, uint32_t &word)
+{
+    const float ch[3] = {c.x, c.y, c.z};
+    uint32_t bits[3];
+    std::memcpy(bits, ch, 12);
+    if (bits[0] == 0 && bits[1] == 0 && bits[2] == 0) { word = 0; return true; }
+    for (int i = 0; i < 3; i++)
+        if (!(ch[i] >= 0.0f) || std::isinf(ch[i]) || bits[i] == 0x80000000u) return false;
+    int e = 0;
+    (void)std::frexp(std::max(ch[0], std::max(ch[1], ch[2])), &e);
+    const int E = e + 128;
+    if (E < 10 || E > 255) return false;
+    uint32_t m[3];
+    for (int i = 0; i < 3; i++) {
+        const float v = std::ldexp(ch[i], 8 - e);
+        if (!(v >= 0.0f && v < 256.0f) || v != std::floor(v)) return false;
+        m[i] = (uint32_t)v;
+        const uint32_t sb = (uint32_t)(E - 9) << 23;
+        float scale, back;
+        std::memcpy(&scale, &sb, 4);
+        back = (float)m[i] * scale;
+        if (std::memcmp(&back, &ch[i], 4) != 0) return false;
+    }
+    word = m[0] | (m[1] << 8) | (m[2] << 16) | ((uint32_t)E << 24);
+    return word != 0;
 }
 
 template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const T **dptr, size_t pad_elems = 0)
@@ -545,6 +582,12 @@ void pt_ctx_destroy(pt_ctx *ctx)
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+int pt_env_is_packed(const pt_ctx *ctx)
+{
+    if (!ctx || !ctx->have_scene) return PT_ERR_STATE;
+    return ctx->sc.envp ? 1 : 0;
+}
+
 void *pt_stream(pt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
@@ -574,6 +617,7 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
         return PT_OK;
+    case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
 }
@@ -716,7 +760,25 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             if (s->env_conditional[i] >= H) return fail(ctx, PT_ERR_ARG, "env_conditional[%zu] out of range", i);
             cond[i] = (uint16_t)s->env_conditional[i];
         }
-        if ((rc = upload(ctx, tex, &sc.env)) != PT_OK) return rc;
+        // shared-exponent packing of the texels, kept only if it reproduces every texel bit for bit
+        const size_t TX = (W + 3) / 4, TY = (H + 3) / 4;
+        std::vector<uint2> packed(TX * TY * 16, make_uint2(0u, 0u));
+        bool exact = true;
+        for (size_t y = 0; y < H && exact; y++)
+            for (size_t x = 0; x < W; x++) {
+                const float4 c = tex[y * W + x];
+                uint32_t word;
+                if (!pack_shared_exponent(c, word)) { exact = false; break; }
+                uint32_t pdf_bits;
+                std::memcpy(&pdf_bits, &c.w, 4);
+                packed[((y >> 2) * TX + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)] = make_uint2(word, pdf_bits);
+            }
+        if (exact && ctx->env_pack) {
+            if ((rc = upload(ctx, packed, &sc.envp)) != PT_OK) return rc;
+            sc.env_tiles_x = (uint32_t)TX;
+        } else {
+            if ((rc = upload(ctx, tex, &sc.env)) != PT_OK) return rc;
+        }
         if ((rc = upload(ctx, marg, &sc.marg)) != PT_OK) return rc;
         if ((rc = upload(ctx, cond, &sc.cond)) != PT_OK) return rc;
         sc.envW = s->env_width;

@@ -119,6 +119,9 @@ typedef struct pt_ctx pt_ctx;
                                        slots refilled; 1: one 64-ray batch per wave step, loop-per-phase traversal */
 #define PT_OPT_TUNE_REFILL_IDLE 6   /* extend tuning: refill a wave's ray slots once this many lanes are empty */
 #define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 26) */
+#define PT_OPT_ENV_PACK         8   /* 1 (default): keep environment texels as shared-exponent word + pdf (8 B, tiled)
+                                       when that reproduces every texel exactly; 0: always 16 B float texels.
+                                       Read by pt_scene_upload. */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 
@@ -162,6 +165,10 @@ int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcp
  * sample per pixel rendered at a time (see PT_OPT_SLAB_BYTES). */
 int  pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint64_t seed,
                pt_stats *stats);
+
+/* 1 when the uploaded scene keeps its environment texels in the packed form (see PT_OPT_ENV_PACK), 0 when not,
+ * negative without a scene.  No reference counterpart. */
+int  pt_env_is_packed(const pt_ctx *ctx);
 
 /* Stream the ctx launches on (a hipStream_t), for callers that want to order their own work after it. */
 void *pt_stream(pt_ctx *ctx);

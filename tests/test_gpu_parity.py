@@ -104,8 +104,8 @@ def film_metrics(a, b):
 
 
 # Film tolerance against the oracle at equal spp and equal seed.  Both sides draw the same random numbers, so a pixel
-# differs only through ulp-level differences between the device's and libm's sin/cos/atan2/acos/pow and the order of
-# the float atomics (about 1e-5 relative), except where such a difference flips a discrete decision of one path (a
+# differs only through ulp-level differences between the device's and libm's sin/cos/atan2/acos/pow
+# (about 1e-5 relative), except where such a difference flips a discrete decision of one path (a
 # silhouette hit on a sub-pixel triangle, a Russian-roulette or lobe choice) and that path's whole contribution changes.
 # Measured on MI355X: about 0.07 % of the paths (0.54 % of the pixels at 8 spp, 0.17 % at 2 spp).  Stated bar: the
 # share of pixels differing by more than 1e-3 relative is at most 0.2 % per sample per pixel, and the relMSE against
@@ -190,7 +190,29 @@ def test_render_small_pool_many_iterations(pkg, ctx):
     ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
     assert st.iterations >= W * H * spp // 1024
     assert st.paths == W * H * spp
-    assert np.allclose(small, big, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(small, big), "the film depends on the pool size"
+
+
+def test_packed_environment_texels_change_nothing(pkg):
+    """A map decoded from a Radiance .hdr file is kept as 8-byte texels (shared-exponent rgb + pdf); the film is bit
+    for bit the one rendered from the 16-byte float texels.  A map of arbitrary floats is not packed."""
+    W, H, spp = 96, 64, 4
+    scene = pkg.HostScene(S.scene_file(pkg, "balls"), W, H)
+    films = []
+    for pack in (1, 0):
+        c = pkg.Context(0)
+        c.set_option(pkg.OPT_ENV_PACK, pack)
+        c.upload(scene)
+        assert c.env_is_packed == bool(pack)
+        c.film_bind(W, H)
+        c.render(0, spp, spp, seed=11)
+        films.append(c.film_download())
+        c.close()
+    assert np.array_equal(films[0], films[1])
+    c = pkg.Context(0)
+    c.upload(S.knot_scene(pkg, W, H))
+    assert not c.env_is_packed
+    c.close()
 
 
 def test_render_in_several_slabs(pkg, ctx):

@@ -5,6 +5,7 @@
 name=$1; pat=$2; shift 2
 R=$PWD
 export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/$name
 cd /tmp
 passes=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU"
