@@ -137,12 +137,13 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 ma
 // same-address atomics are what this kernel would otherwise wait for.
 // --------------------------------------------------------------------------------------------------------------
 constexpr int kBounceBlock = 512;
-constexpr int kBounceWaves = kBounceBlock / 64;
 
+template <int kBounceBlock>
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
                                                          uint32_t npix, float spp_total, uint32_t seed0, uint32_t seed1)
 {
+    constexpr int kBounceWaves = kBounceBlock / 64;
     __shared__ uint32_t s_wave[2][kBounceWaves];
     __shared__ uint32_t s_base[2];
     const uint32_t n = cnt->n_in;
@@ -347,6 +348,7 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
+    int bounce_block = 512;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;
     size_t gstk_threads = 0;
@@ -617,6 +619,7 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
         return PT_OK;
+    case 9: ctx->bounce_block = (int)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1013,8 +1016,13 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         while (!done) {
             PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
             if (it > 0)
-                hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab,
-                                   (uint32_t)first, npix, (float)spp_total, s0, s1);
+            {
+                const int bb = ctx->bounce_block;
+                const int g2 = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / bb), ((uint64_t)P + bb - 1) / bb));
+                if (bb == 256) hipLaunchKernelGGL(k_bounce<256>, dim3(g2), dim3(256), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
+                else if (bb == 1024) hipLaunchKernelGGL(k_bounce<1024>, dim3(g2), dim3(1024), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
+                else hipLaunchKernelGGL(k_bounce<512>, dim3(g2), dim3(512), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
+            }
             hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
                                s1, ctx->slab, (float)spp_total);
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
