@@ -81,9 +81,11 @@ __device__ __forceinline__ float4 material_of(const DScene &sc, uint32_t prim)
 // environment in the ray's direction over the sample count (reference src/render.cu:62-72).  Every kernel that creates
 // a ray stores this value in the path's slab entry right away; a later bounce of the same path overwrites it, so the
 // entry holds the right value whenever the path ends, and ending a path costs no environment lookup.
-__device__ __forceinline__ float4 escape_value(float4 th, float4 e, float spp_total)
+// The division by the sample count of src/render.cu:68 is applied when the slab is summed (k_film_reduce), on the very
+// same product, so the quotient is the same float; here it would be 33 instructions in kernels that have none to spare.
+__device__ __forceinline__ float4 escape_value(float4 th, float4 e)
 {
-    return make_float4(th.x * e.x / spp_total, th.y * e.y / spp_total, th.z * e.z / spp_total, 0.0f);
+    return make_float4(th.x * e.x, th.y * e.y, th.z * e.z, 0.0f);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -136,12 +138,13 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 ma
 // kBounceBlock threads claims its output range with ONE atomic, because every block adds to the same counter and
 // same-address atomics are what this kernel would otherwise wait for.
 // --------------------------------------------------------------------------------------------------------------
+// threads per block = rays per output claim.  Measured ms per frame (dragon stand-in / spheres only) for 256, 512, 1024:
+// 342 / 335 / 341 and 124 / 117 / 121.
 constexpr int kBounceBlock = 512;
 
-template <int kBounceBlock>
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
-                                                         uint32_t npix, float spp_total, uint32_t seed0, uint32_t seed1)
+                                                         uint32_t npix, uint32_t seed0, uint32_t seed1)
 {
     constexpr int kBounceWaves = kBounceBlock / 64;
     __shared__ uint32_t s_wave[2][kBounceWaves];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
             else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
-            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e, spp_total);
+            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e);
             th.w = __uint_as_float(sample | ((k + 1) << 27));
         }
         if (threadIdx.x == 0) s_base[par] = claimed;
@@ -238,7 +241,7 @@ __device__ __forceinline__ void new_take(const Counters *cnt, uint32_t P, uint32
 
 __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const Counters *cnt, uint32_t P, uint32_t W,
                                                      uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
-                                                     float4 *__restrict__ slab, float spp_total)
+                                                     float4 *__restrict__ slab)
 {
     uint32_t n_out, take;
     new_take(cnt, P, n_out, take);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const
         camera_ray(sc.cam, W, H, x, y, rng, o, d);
         const uint32_t dst = n_out + j;
         const float4 th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-        slab[(size_t)s_local * npix + pixel] = escape_value(th, env_lookup(sc, d), spp_total);
+        slab[(size_t)s_local * npix + pixel] = escape_value(th, env_lookup(sc, d));
         B.o[dst] = make_float4(o.x, o.y, o.z, 0.0f);
         B.d[dst] = make_float4(d.x, d.y, d.z, __uint_as_float(pixel));
         B.thr[dst] = th;
@@ -280,16 +283,17 @@ __global__ void k_advance(Counters *cnt, uint32_t P)
     cnt->n_out = 0;
 }
 
-// Sums a pixel's slab entries in sample order and adds the sum to the film (float3 per pixel, row 0 = top).
+// Divides a pixel's slab entries by the sample count, sums them in sample order and adds the sum to the film (float3
+// per pixel, row 0 = top).
 __global__ __launch_bounds__(kBlock) void k_film_reduce(const float4 *__restrict__ slab, uint32_t nsamples, uint32_t npix,
-                                                        float *__restrict__ film)
+                                                        float spp_total, float *__restrict__ film)
 {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < npix; p += gridDim.x * kBlock) {
         float r = 0.0f, g = 0.0f, b = 0.0f;
         const float4 *src = slab + p;
         for (uint32_t s = 0; s < nsamples; s++) {
             const float4 v = src[(size_t)s * npix];
-            r += v.x; g += v.y; b += v.z;
+            r += v.x / spp_total; g += v.y / spp_total; b += v.z / spp_total;
         }
         float *px = film + 3 * (size_t)p;
         px[0] += r; px[1] += g; px[2] += b;
@@ -348,7 +352,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    int bounce_block = 512;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;
     size_t gstk_threads = 0;
@@ -619,7 +622,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
         return PT_OK;
-    case 9: ctx->bounce_block = (int)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1016,15 +1018,10 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         while (!done) {
             PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
             if (it > 0)
-            {
-                const int bb = ctx->bounce_block;
-                const int g2 = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / bb), ((uint64_t)P + bb - 1) / bb));
-                if (bb == 256) hipLaunchKernelGGL(k_bounce<256>, dim3(g2), dim3(256), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
-                else if (bb == 1024) hipLaunchKernelGGL(k_bounce<1024>, dim3(g2), dim3(1024), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
-                else hipLaunchKernelGGL(k_bounce<512>, dim3(g2), dim3(512), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab, (uint32_t)first, npix, (float)spp_total, s0, s1);
-            }
+                hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab,
+                                   (uint32_t)first, npix, s0, s1);
             hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
-                               s1, ctx->slab, (float)spp_total);
+                               s1, ctx->slab);
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
             if (ctx->time_extend) {
                 while (ctx->events.size() < ev_used + 2) {
@@ -1057,7 +1054,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         }
         // every path of this slab has ended and stored its contribution: fold the slab into the film
         hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count, npix,
-                           ctx->film);
+                           (float)spp_total, ctx->film);
         HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[0], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, hipGetLastError());
