@@ -144,7 +144,7 @@ constexpr int kBounceBlock = 512;
 
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
-                                                         uint32_t npix, uint32_t seed0, uint32_t seed1, uint32_t dbg)
+                                                         uint32_t npix, uint32_t seed0, uint32_t seed1)
 {
     constexpr int kBounceWaves = kBounceBlock / 64;
     __shared__ uint32_t s_wave[2][kBounceWaves];
@@ -210,17 +210,16 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
             float4 e;
-            if (dbg & 1) { out = reflect3(d, n3); e = make_float4(0.5f, 0.5f, 0.5f, 1.0f); }
-            else if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
+            if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
             else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
             else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
-            if (!(dbg & 2)) slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e);
+            slab[(size_t)(sample - slab_first_sample) * npix + pixel] = escape_value(th, e);
             th.w = __uint_as_float(sample | ((k + 1) << 27));
         }
         if (threadIdx.x == 0) s_base[par] = claimed;
         __syncthreads();
-        if (alive && !(dbg & 4)) {
+        if (alive) {
             const uint32_t dst = s_base[par] + r;
             B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
             B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
@@ -353,7 +352,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    uint32_t dbg = 0;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;
     size_t gstk_threads = 0;
@@ -624,7 +622,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
         return PT_OK;
-    case 9: ctx->dbg = (uint32_t)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1022,7 +1019,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
             PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
             if (it > 0)
                 hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab,
-                                   (uint32_t)first, npix, s0, s1, ctx->dbg);
+                                   (uint32_t)first, npix, s0, s1);
             hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
                                s1, ctx->slab);
             hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
