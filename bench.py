@@ -126,7 +126,7 @@ def main():
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
         mrays = total_rays / elapsed / 1e6
         out = {
-            "metric": "Mrays/s (ms/frame in ms_per_step), dragon 1920x1080 512spp",
+            "metric": "Mrays/s (ms/frame in ms_per_step), %s %dx%d %dspp" % (args.scene, args.width, args.height, args.spp),
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -175,7 +175,13 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r1_extend_traffic.json")
         if os.path.exists(tpath) and args.scene == "dragon" and (args.width, args.height, args.spp) == (1920, 1080, 512):
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+            prof = json.load(open(tpath))
+            if world == 1:
+                traffic = prof.get("traffic_bytes_per_launch")
+            if b_ray is None:
+                # the oracle's per-ray traversal means of this workload are deterministic; without the CPU leg (N > 1 or
+                # --no-cpu-baseline) the committed figure of the same workload is used
+                b_ray = prof.get("algorithmic_bytes_per_ray")
         if b_ray is not None and acc["ms_extend"] > 0:
             achieved = b_ray * acc["rays"] / (acc["ms_extend"] * 1e-3) / 1e9
             out["roofline"] = {
