@@ -93,8 +93,11 @@ struct Rng {
         uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < 10; r++) {
-            uint32_t h0 = __umulhi(0xD2511F53u, x0), l0 = 0xD2511F53u * x0;
-            uint32_t h1 = __umulhi(0xCD9E8D57u, x2), l1 = 0xCD9E8D57u * x2;
+            // one 32x32->64 multiply per product (v_mad_u64_u32) instead of separate high and low halves: 32-bit
+            // integer multiplies are quarter rate here and this generator is most of the shading kernels' arithmetic
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+            uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+            uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
             x0 = h1 ^ x1 ^ a; x1 = l1; x2 = h0 ^ x3 ^ b; x3 = l0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
@@ -218,6 +221,12 @@ __device__ __forceinline__ float4 env_texel(const DScene &sc, int x, int y)
     return sc.env[(size_t)y * sc.envW + x];
 }
 
+__device__ __forceinline__ int wrap_index(int i, int n)
+{
+    if (i >= -n && i < 2 * n) return i < 0 ? i + n : (i >= n ? i - n : i);
+    return ((i % n) + n) % n;
+}
+
 // fp32 bilinear fetch with wrap addressing at normalised coordinates (reference src/environment_map.cu:156-162)
 __device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float theta)
 {
@@ -227,8 +236,10 @@ __device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float t
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
     int ix = (int)fx0, iy = (int)fy0;
-    int x0 = ((ix % W) + W) % W, x1 = (x0 + 1) % W;
-    int y0 = ((iy % H) + H) % H, y1 = (y0 + 1) % H;
+    // wrap addressing.  Coordinates in [0,1] give indices in [-1, size]; one conditional add or subtract is the modulo
+    // there, and integer division (35 instructions each on this chip) is left to indices outside [-size, 2 size).
+    int x0 = wrap_index(ix, W), x1 = x0 + 1 == W ? 0 : x0 + 1;
+    int y0 = wrap_index(iy, H), y1 = y0 + 1 == H ? 0 : y0 + 1;
     const float4 t00 = env_texel(sc, x0, y0), t10 = env_texel(sc, x1, y0);
     const float4 t01 = env_texel(sc, x0, y1), t11 = env_texel(sc, x1, y1);
     float4 r;
@@ -325,17 +336,30 @@ __device__ __forceinline__ void camera_ray(const pt_camera &c, uint32_t W, uint3
     }
 }
 
+// floor(a / b) for a < 2^53, b < 2^32, b != 0 through one double-precision multiply and a one-step correction: the integer
+// division sequences of this chip are 40 (32-bit) to 150 (64-bit) instructions, and the generate kernel is bound by its
+// instruction count.
+__device__ __forceinline__ unsigned long long udiv_wide(unsigned long long a, uint32_t b)
+{
+    unsigned long long q = (unsigned long long)((double)a * (1.0 / (double)b));
+    // the estimate is off by at most one either way
+    if (q * b > a) q--;
+    else if ((q + 1) * b <= a) q++;
+    return q;
+}
+__device__ __forceinline__ uint32_t udiv_small(uint32_t a, uint32_t b) { return (uint32_t)udiv_wide(a, b); }
+
 // Sample-major enumeration of the film: index r in [0, W*H) -> pixel.  When the film tiles into 8x4 blocks a wave's
 // 64 consecutive indices cover a 16x4 patch, which keeps primary rays of a wave close together.
 __device__ __forceinline__ void pixel_of(uint32_t r, uint32_t W, uint32_t H, uint32_t &x, uint32_t &y)
 {
     if ((W & 7u) == 0 && (H & 3u) == 0) {
         uint32_t tile = r >> 5, in = r & 31u, tpr = W >> 3;
-        uint32_t ty = tile / tpr, tx = tile - ty * tpr;
+        uint32_t ty = udiv_small(tile, tpr), tx = tile - ty * tpr;
         x = tx * 8 + (in & 7u);
         y = ty * 4 + (in >> 3);
     } else {
-        y = r / W;
+        y = udiv_small(r, W);
         x = r - y * W;
     }
 }

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < take; j += stride) {
         const unsigned long long g = first + j;
-        const uint32_t s_local = (uint32_t)(g / npix);
+        const uint32_t s_local = (uint32_t)udiv_wide(g, npix);
         const uint32_t r = (uint32_t)(g - (unsigned long long)s_local * npix);
         const uint32_t sample = spp_begin + s_local;
         uint32_t x, y;
