@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=512)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "balls"])
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "balls", "city", "synth"])
+    ap.add_argument("--instances", type=int, default=116,
+                    help="--scene synth: copies of the dragon stand-in flattened into one mesh (116 = 100.7 M triangles)")
     ap.add_argument("--pool", type=int, default=0, help="path slots in flight (0: library default)")
     ap.add_argument("--extend-mode", type=int, default=2, help="2 persistent single-step waves (default), 1 loop-per-phase batches")
     ap.add_argument("--tune", default="", help="comma list of option=value pairs passed to pt_set_option")
@@ -63,13 +65,20 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # scene assembly (host, untimed): rank 0 generates the cached assets, the others wait
+    file_scene = "dragon" if args.scene == "synth" else args.scene
     if rank == 0:
-        scene_path = S.scene_file(pkg, args.scene)
+        scene_path = S.scene_file(pkg, file_scene)
     if world > 1:
         dist.barrier()
-    scene_path = S.scene_file(pkg, args.scene)
+    scene_path = S.scene_file(pkg, file_scene)
+
+    def make_scene(w, h):
+        if args.scene == "synth":
+            return S.instanced_scene(pkg, w, h, args.instances)[0]
+        return pkg.HostScene(scene_path, w, h)
+
     t0 = time.time()
-    scene = pkg.HostScene(scene_path, args.width, args.height)
+    scene = make_scene(args.width, args.height)
     t_scene = time.time() - t0
 
     ctx = pkg.Context(local_rank)
@@ -139,8 +148,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s.scene %dx%d %d spp (procedural stand-ins for the unshipped dragon.obj/forest.hdr)"
-                            % (args.scene, args.width, args.height, args.spp),
+                "workload": "%s %dx%d %d spp (procedural stand-ins for the unshipped dragon.obj and .hdr maps)"
+                            % ("%d-instance dragon stand-in" % args.instances if args.scene == "synth" else args.scene + ".scene",
+                               args.width, args.height, args.spp),
                 "triangles": int(scene.desc.num_tris),
                 "rays_per_frame": int(total_rays / max(1, args.steps)),
                 "parallelism": "spp-partition x%d + film reduce" % world,
@@ -154,7 +164,7 @@ def main():
             import oracle_lib as O
 
             cw, ch, cspp = 960, 540, 48
-            cscene = pkg.HostScene(scene_path, cw, ch)
+            cscene = make_scene(cw, ch)
             threads = min(os.cpu_count() or 1, 16)
             _, ost = O.render(S.as_oracle_desc(cscene), cw, ch, 0, cspp, cspp, seed=1, nthreads=threads)
             cpu = {

@@ -156,9 +156,32 @@ specular 1 1 1
 glossyness 0.05
 file_name {dragon}
 """,
+    # reference scene/city.scene
+    "city": """CAMERA
+position -10 12 10
+look_at 0 2 0
+fov 38
+aperture 0.05
+focus_dist 15
+
+ENVIRONMENT
+file_name {studio}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.1 0.08 0.15
+position 0 0 0
+normal 0 1 0
+
+OBJ
+material_type LAMBERTIAN
+albedo 0.7 0.7 0.7
+file_name {city}
+""",
 }
 
-_SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"]}
+_SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"],
+                 "city": ["studio.hdr"]}
 
 
 def scene_file(pkg, name):
@@ -166,8 +189,8 @@ def scene_file(pkg, name):
     paths = {}
     for kind in _SCENE_ASSETS[name]:
         paths[kind.split(".")[0]] = ensure_asset(pkg, kind)
-    if name == "bunny":
-        paths["bunny"] = ensure_mesh_obj("bunny")
+    if name in ("bunny", "city"):
+        paths[name] = ensure_mesh_obj(name)
     path = os.path.join(asset_dir(), name + ".scene")
     text = SCENE_TEXT[name].format(**paths)
     if not os.path.exists(path) or open(path).read() != text:
@@ -216,6 +239,57 @@ def knot_scene(pkg, width, height, mesh_type=None, with_spheres=True):
     return pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
                            mesh_material=(0.65, 0.65, 0.65, 0.05),
                            mesh_material_type=pkg.GLOSSY if mesh_type is None else mesh_type)
+
+
+_INSTANCED = {}
+
+
+def instanced_scene(pkg, width, height, instances, base="dragon.obj"):
+    """The stress configuration: `instances` copies of the dragon stand-in (868,352 triangles each; 116 copies are
+    100.7 M triangles) on a square grid, flattened into ONE triangle mesh and one BVH as the reference would see it,
+    glossy, with glass spheres between the copies (the reference has one material per mesh, so glossy + glass means a
+    glossy mesh plus glass spheres), the dragon scene's plane and the forest map.  Returns (scene, triangle count)."""
+    import math
+    side = int(math.ceil(math.sqrt(instances)))
+    key = (instances, base)
+    if key not in _INSTANCED:
+        base_tris = pkg.obj_load(ensure_asset(pkg, base))          # (n, 3, 3)
+        lo = base_tris.reshape(-1, 3).min(axis=0)
+        hi = base_tris.reshape(-1, 3).max(axis=0)
+        pitch = 1.15 * float(max(hi[0] - lo[0], hi[2] - lo[2]))
+        n = base_tris.shape[0]
+        tris = np.empty((instances * n, 3, 3), dtype=np.float32)
+        centres = []
+        for k in range(instances):
+            gx, gz = k % side, k // side
+            off = np.array([(gx - 0.5 * (side - 1)) * pitch, 0.0, (gz - 0.5 * (side - 1)) * pitch], dtype=np.float32)
+            np.add(base_tris, off, out=tris[k * n:(k + 1) * n])
+            if gx + 1 < side and gz + 1 < side and len(centres) < 64:
+                centres.append((float(off[0] + 0.5 * pitch), float(lo[1]) + 0.12, float(off[2] + 0.5 * pitch)))
+        bvh = pkg.bvh_build(tris, threads=min(16, os.cpu_count() or 1))
+        ntris = tris.shape[0]
+        del tris
+        _INSTANCED.clear()                     # one mesh of this size at a time
+        _INSTANCED[key] = (bvh, ntris, centres, float(lo[1]), pitch)
+    bvh, ntris, centres, floor_y, pitch = _INSTANCED[key]
+    spheres = [pkg.make_sphere(c, 0.12, (1.0, 1.0, 1.0, 1.5), pkg.GLASS) for c in centres]
+    extent = 0.5 * side * pitch
+    cam = pkg.camera_make((-1.6 * extent - 0.8, 0.9 * extent + 0.3, -1.3 * extent - 0.6), (0.0, 0.0, 0.0), 38.0,
+                          width / height, 0.01, 2.2 * extent + 1.0)
+    tex, marg, cond = hdr_env(pkg, "forest.hdr")
+    planes = [pkg.make_plane((0, floor_y, 0), (0, 1, 0), (0.65, 0.1, 0.1, 0.0), pkg.DIFFUSE)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
+                            mesh_material=(0.65, 0.65, 0.65, 0.05), mesh_material_type=pkg.GLOSSY)
+    return scene, ntris
+
+
+def hdr_env(pkg, kind):
+    """(texels with pdf, marginal table, conditional table) of one of the generated .hdr maps."""
+    rgb = pkg.hdr_load(ensure_asset(pkg, kind))
+    tex = np.zeros(rgb.shape[:2] + (4,), dtype=np.float32)
+    tex[..., :3] = rgb[..., :3]
+    marg, cond = pkg.env_build(tex)
+    return tex, marg, cond
 
 
 def mesh_scene(pkg, tris, width, height, cam_pos, look_at, fov=35.0, aperture=0.0, focus=4.0,

@@ -53,6 +53,27 @@ def test_intersect_matches_oracle_on_shipped_meshes(pkg, ctx, mesh, cam):
     assert (prim != O.PRIM_MISS).mean() > 0.3
 
 
+def test_instanced_stress_scene_matches_oracle(pkg, ctx):
+    """The 8-GPU stress configuration in small: 9 copies of the 9,216-triangle knot flattened into one glossy mesh with
+    glass spheres between them.  Hits bit-equal to the oracle on primary + bounced rays, film within the stated bar."""
+    W, H, spp = 128, 72, 4
+    scene, ntris = S.instanced_scene(pkg, W, H, 9, base="knot_small.obj")
+    assert ntris == 9 * 9216 and scene.desc.num_spheres == 4
+    org, dir_ = S.ray_batch(scene, W, H, seed=8)
+    ctx.upload(scene)
+    t, prim, _ = ctx.intersect(org, dir_)
+    ot, oprim, _, _ = O.intersect(S.as_oracle_desc(scene), org, dir_)
+    check_hits(t, prim, ot, oprim, "instanced")
+    assert np.array_equal(t, ot)
+    assert ctx.env_is_packed                      # the forest map comes from an .hdr file
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=4)
+    film = ctx.film_download()
+    ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=4)
+    _, differing = film_metrics(film, ofilm)
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+
+
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
     """The loop-per-phase batch kernel and the persistent single-step kernel must agree bit for bit with the fixture."""
     scene = S.parity_cases(pkg)["knot"]
@@ -115,10 +136,13 @@ MAX_FLIPPED_PATH_RATE = 0.002
 MAX_RELMSE_OVER_NOISE = 0.05
 
 
-@pytest.mark.parametrize("name", ["knot", "balls"])
+@pytest.mark.parametrize("name", ["knot", "balls", "city"])
 def test_render_matches_oracle(pkg, ctx, name):
     W, H, spp = 96, 64, 8
-    scene = S.knot_scene(pkg, W, H) if name == "knot" else S.spheres_scene(pkg, W, H)
+    if name == "city":                               # reference scene/city.scene with the shipped mesh
+        scene = pkg.HostScene(S.scene_file(pkg, "city"), W, H)
+    else:
+        scene = S.knot_scene(pkg, W, H) if name == "knot" else S.spheres_scene(pkg, W, H)
     ctx.upload(scene)
     ctx.film_bind(W, H)
     st = ctx.render(0, spp, spp, seed=5)
