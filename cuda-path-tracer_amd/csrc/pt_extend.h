@@ -36,7 +36,6 @@ struct ExtendArgs {
     float *t_out;              // hit distance, FLT_MAX on a miss
     unsigned long long *cnt3;  // nodes, triangles, leaves (COUNT only)
     int refill_idle;
-    int xcd_groups;            // 1: chunk -> wave mapping that keeps an XCD's waves on consecutive chunks
     int lds_slots;             // traversal stack slots per lane kept in LDS
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
 };
@@ -262,13 +261,6 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
     // wave-uniform cursor over this wave's chunks of the ray buffer
     uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    if (a.xcd_groups && (gridDim.x & 7u) == 0) {
-        // Workgroups go to the 8 XCDs round robin.  Let the waves of one XCD take consecutive chunks, so that the rays in
-        // flight under one L2 are neighbours in the ray buffer (neighbours on screen, for the first bounces).
-        const uint32_t per_xcd = nwaves >> 3;
-        chunk = __builtin_amdgcn_readfirstlane((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) * (kBlock >> 6) +
-                                               (threadIdx.x >> 6));
-    }
     uint32_t next = chunk * kChunk;
     uint32_t end = next < n ? min(n, next + kChunk) : next;
 

@@ -352,7 +352,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    int xcd_groups = 1;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;
     size_t gstk_threads = 0;
@@ -510,7 +509,6 @@ static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const 
     a.hid_out = hid; a.t_out = t;
     a.cnt3 = &ctx->cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
-    a.xcd_groups = ctx->xcd_groups;
     a.lds_slots = lds_slots;
     a.gstk = ctx->gstk;
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
@@ -624,7 +622,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
         return PT_OK;
-    case 9: ctx->xcd_groups = value != 0; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
