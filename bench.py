@@ -58,7 +58,11 @@ def main():
     import cuda_path_tracer_amd.distributed as D
     import scenes as S
 
-    rank, world, local_rank = D.init_from_env()
+    # PT_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo for the collectives, to run the N > 1 code path on a one-GPU box
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    rank, world, local_rank = D.init_from_env("gloo" if rehearsal else None)
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
