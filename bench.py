@@ -89,20 +89,24 @@ def main():
     if args.pool:
         ctx.set_option(pkg.OPT_POOL_SIZE, args.pool)
     ctx.set_option(pkg.OPT_EXTEND_MODE, args.extend_mode)
+    streams = 3                                    # the library's default
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         ctx.set_option(int(k), int(v))
+        if int(k) == pkg.OPT_STREAMS:
+            streams = int(v)
     ctx.upload(scene)
     film = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
     ctx.film_bind(args.width, args.height, film.data_ptr())
     torch.cuda.synchronize()
 
-    acc = {"rays": 0, "ms_extend": 0.0, "launches": 0, "ms_render": 0.0}
+    acc = {"rays": 0, "ms_extend": 0.0, "ms_extend_busy": 0.0, "launches": 0, "ms_render": 0.0}
 
     def render_fn(begin, count, total, seed):
         st = ctx.render(begin, count, total, seed)
         acc["rays"] += st.rays
         acc["ms_extend"] += st.ms_extend
+        acc["ms_extend_busy"] += st.ms_extend_busy
         acc["launches"] += st.iterations
         acc["ms_render"] += st.ms_total
         return st
@@ -205,7 +209,14 @@ def main():
                 "avg_launch_ms": round(acc["ms_extend"] / max(1, acc["launches"]), 4),
                 "launches": int(acc["launches"]),
                 "rays_per_launch": round(acc["rays"] / max(1, acc["launches"]), 1),
-                "extend_share_of_frame": round(acc["ms_extend"] / max(1e-9, acc["ms_render"]), 3),
+                # The library runs several wavefront loops on streams of their own, so extend launches overlap each other
+                # (and the other kernels): a launch then has only part of the device and its own duration understates what
+                # the device does.  achieved_all_streams divides the same bytes by the time during which at least one
+                # extend launch was running.
+                "concurrent_streams": streams,
+                "achieved_all_streams": round(b_ray * acc["rays"] / (acc["ms_extend_busy"] * 1e-3) / 1e9, 1),
+                "frac_all_streams": round(b_ray * acc["rays"] / (acc["ms_extend_busy"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "extend_busy_share_of_frame": round(acc["ms_extend_busy"] / max(1e-9, acc["ms_render"]), 3),
             }
         else:
             out["roofline"] = None

@@ -17,6 +17,7 @@ PRIM_MISS, PRIM_PLANE, PRIM_SPHERE = 0xFFFFFFFF, 0x80000000, 0x40000000
 OPT_POOL_SIZE, OPT_COUNT_TRAVERSAL, OPT_TIME_EXTEND, OPT_SLAB_BYTES, OPT_EXTEND_MODE = 1, 2, 3, 4, 5
 OPT_TUNE_REFILL_IDLE, OPT_TUNE_LDS_SLOTS = 6, 7
 OPT_ENV_PACK = 8
+OPT_STREAMS = 9
 
 
 class Plane(C.Structure):
@@ -50,7 +51,8 @@ class SceneDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("iterations", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
-                ("nodes", C.c_uint64), ("tris", C.c_uint64), ("leaves", C.c_uint64)]
+                ("nodes", C.c_uint64), ("tris", C.c_uint64), ("leaves", C.c_uint64),
+                ("ms_extend_busy", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -334,6 +334,28 @@ __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint3
 // ================================================================================================================
 // host side
 // ================================================================================================================
+// One independent wavefront (own stream, path buffers and counters) rendering a share of the samples.
+constexpr int kMaxLanes = 4;
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint32_t pool_alloc = 0;
+    PathBuf buf[2]{};
+    Counters *cnt = nullptr;
+    Counters *h_cnt = nullptr;     // pinned: 4 polling slots + 1 initial value
+    int *gstk = nullptr;           // traversal stack overflow of this lane's extend launches
+    size_t gstk_threads = 0;
+    std::vector<hipEvent_t> events;
+    hipEvent_t poll_ev[4]{};
+    hipEvent_t ev_done = nullptr;
+    // state of the slab share being rendered
+    uint64_t first = 0, count = 0, total = 0, min_iters = 0, it = 0;
+    uint32_t P = 0;
+    float4 *slab = nullptr;
+    size_t ev_used = 0;
+    int cur = 0;
+    bool done = true;
+};
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -353,7 +375,7 @@ struct pt_ctx {
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
     bool env_pack = true;      // use the packed environment texels when they are exact
-    int *gstk = nullptr;
+    int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
     size_t tmp_hid_n = 0;
@@ -368,14 +390,12 @@ struct pt_ctx {
     size_t slab_bytes = 0;
     uint64_t slab_budget = 32ull << 30;
 
-    // wavefront state
-    uint32_t pool_alloc = 0;
-    PathBuf buf[2]{};
-    Counters *cnt = nullptr;
-    Counters *h_cnt = nullptr;     // pinned, 4 slots
-    std::vector<hipEvent_t> events;
-    hipEvent_t poll_ev[4]{};
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    // wavefront state: one lane per stream (see pt_render)
+    int nlanes = 3;
+    Lane lanes[kMaxLanes];
+    Counters *cnt = nullptr;       // counters of the closest-hit entry points
+    Counters *h_cnt = nullptr;     // pinned
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_slab_free = nullptr;
 };
 
 static thread_local std::string g_create_err;
@@ -406,29 +426,29 @@ static int stream_grid(const pt_ctx *ctx, uint64_t n)
     return (int)std::max<uint64_t>(1, std::min(cap, need));
 }
 
-static void free_pool(pt_ctx *ctx)
+static void free_pool(Lane &ln)
 {
-    for (auto &b : ctx->buf) {
+    for (auto &b : ln.buf) {
         (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hid); (void)hipFree(b.t);
         b = PathBuf{};
     }
-    ctx->pool_alloc = 0;
+    ln.pool_alloc = 0;
 }
 
-// Grow-only: the buffers hold at least `slots` paths afterwards.
-static int ensure_pool(pt_ctx *ctx, uint32_t slots)
+// Grow-only: the lane's buffers hold at least `slots` paths afterwards.
+static int ensure_pool(pt_ctx *ctx, Lane &ln, uint32_t slots)
 {
-    if (ctx->pool_alloc >= slots) return PT_OK;
-    free_pool(ctx);
+    if (ln.pool_alloc >= slots) return PT_OK;
+    free_pool(ln);
     const size_t P = slots;
-    for (auto &b : ctx->buf) {
+    for (auto &b : ln.buf) {
         HIPCHK(ctx, hipMalloc(&b.o, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.d, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.thr, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.hid, P * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
     }
-    ctx->pool_alloc = slots;
+    ln.pool_alloc = slots;
     return PT_OK;
 }
 
@@ -484,8 +504,9 @@ template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const
 // CU holds are 160 KB / that (at most 8).  Trees needing more than ctx->lds_slots slots keep the rest in a global
 // array.  Measured on the 868 k-triangle stand-in (26 slots): 26 slots in LDS, 6 blocks per CU, beat 20 slots + overflow
 // at 8 blocks per CU by 3 %.
-static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const Counters *cnt, uint32_t n_fixed,
-                         uint32_t n_upper, uint32_t *hid, float *t)
+static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_on_device, int **gstk,
+                         size_t *gstk_threads, const float4 *ro, const float4 *rd, uint32_t n_fixed, uint32_t n_upper,
+                         uint32_t *hid, float *t)
 {
     const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
     const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
@@ -496,25 +517,25 @@ static int launch_extend(pt_ctx *ctx, const float4 *ro, const float4 *rd, const 
     const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
     if (overflow) {
         const size_t threads = (size_t)ctx->num_cus * 8 * kBlock;
-        if (!ctx->gstk || ctx->gstk_threads != threads) {
-            if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; }
-            HIPCHK(ctx, hipMalloc(&ctx->gstk, threads * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
-            ctx->gstk_threads = threads;
+        if (!*gstk || *gstk_threads != threads) {
+            if (*gstk) { (void)hipFree(*gstk); *gstk = nullptr; }
+            HIPCHK(ctx, hipMalloc(gstk, threads * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
+            *gstk_threads = threads;
         }
     }
     ExtendArgs a{};
     a.ro = ro; a.rd = rd;
-    a.n_ptr = cnt ? &cnt->n_in : nullptr;
+    a.n_ptr = n_on_device ? &cnt->n_in : nullptr;
     a.n_fixed = n_fixed;
     a.hid_out = hid; a.t_out = t;
-    a.cnt3 = &ctx->cnt->trav[0];
+    a.cnt3 = &cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
-    a.gstk = ctx->gstk;
+    a.gstk = *gstk;
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
-#define PT_LAUNCH(K, OV, CT) hipLaunchKernelGGL((K<OV, CT>), g, b, shmem, ctx->stream, ctx->sc, a)
+#define PT_LAUNCH(K, OV, CT) hipLaunchKernelGGL((K<OV, CT>), g, b, shmem, stream, ctx->sc, a)
     if (ctx->extend_mode == 1) {
         if (overflow) { if (count) PT_LAUNCH(k_extend_batch, true, true); else PT_LAUNCH(k_extend_batch, true, false); }
         else { if (count) PT_LAUNCH(k_extend_batch, false, true); else PT_LAUNCH(k_extend_batch, false, false); }
@@ -555,10 +576,17 @@ int pt_ctx_create(int device, pt_ctx **out)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     CREATECHK(hipMalloc(&ctx->cnt, sizeof(Counters)));
-    CREATECHK(hipHostMalloc(&ctx->h_cnt, 4 * sizeof(Counters)));
-    for (auto &ev : ctx->poll_ev) CREATECHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    CREATECHK(hipHostMalloc(&ctx->h_cnt, sizeof(Counters)));
+    for (auto &ln : ctx->lanes) {
+        CREATECHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        CREATECHK(hipMalloc(&ln.cnt, sizeof(Counters)));
+        CREATECHK(hipHostMalloc(&ln.h_cnt, 5 * sizeof(Counters)));
+        for (auto &ev : ln.poll_ev) CREATECHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        CREATECHK(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+    }
     CREATECHK(hipEventCreate(&ctx->ev_begin));
     CREATECHK(hipEventCreate(&ctx->ev_end));
+    CREATECHK(hipEventCreateWithFlags(&ctx->ev_slab_free, hipEventDisableTiming));
 #undef CREATECHK
     *out = ctx;
     return PT_OK;
@@ -569,18 +597,27 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ln : ctx->lanes) {
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        free_pool(ln);
+        (void)hipFree(ln.cnt);
+        (void)hipFree(ln.gstk);
+        if (ln.h_cnt) (void)hipHostFree(ln.h_cnt);
+        for (auto ev : ln.events) (void)hipEventDestroy(ev);
+        for (auto ev : ln.poll_ev) if (ev) (void)hipEventDestroy(ev);
+        if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
+        if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     free_scene(ctx);
-    free_pool(ctx);
     if (ctx->film_owned) (void)hipFree(ctx->film);
     (void)hipFree(ctx->cnt);
     (void)hipFree(ctx->gstk);
     (void)hipFree(ctx->tmp_hid);
     (void)hipHostFree(ctx->h_cnt);
     (void)hipFree(ctx->slab);
-    for (auto ev : ctx->events) (void)hipEventDestroy(ev);
-    for (auto ev : ctx->poll_ev) if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->ev_slab_free) (void)hipEventDestroy(ctx->ev_slab_free);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -621,6 +658,11 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
     case PT_OPT_TUNE_REFILL_IDLE:
         if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "refill threshold %llu out of [1, 64]", (unsigned long long)value);
         ctx->refill_idle = (int)value;
+        return PT_OK;
+    case PT_OPT_STREAMS:
+        if (value < 1 || value > (uint64_t)kMaxLanes) return fail(ctx, PT_ERR_ARG, "stream count %llu out of [1, %d]",
+                                                                   (unsigned long long)value, kMaxLanes);
+        ctx->nlanes = (int)value;
         return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
@@ -811,8 +853,8 @@ int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void 
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->cnt, 0, sizeof(Counters), ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
-    int rc = launch_extend(ctx, (const float4 *)d_org4, (const float4 *)d_dir4, nullptr, (uint32_t)n, (uint32_t)n,
-                           ctx->tmp_hid, (float *)d_t);
+    int rc = launch_extend(ctx, ctx->stream, ctx->cnt, false, &ctx->gstk, &ctx->gstk_threads, (const float4 *)d_org4,
+                           (const float4 *)d_dir4, (uint32_t)n, (uint32_t)n, ctx->tmp_hid, (float *)d_t);
     if (rc != PT_OK) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
     hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->sc,
@@ -825,7 +867,7 @@ int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void 
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
         stats->rays = n; stats->iterations = 1; stats->extend_launches = 1;
-        stats->ms_total = ms; stats->ms_extend = ms;
+        stats->ms_total = ms; stats->ms_extend = ms; stats->ms_extend_busy = ms;
         stats->nodes = ctx->h_cnt->trav[0]; stats->tris = ctx->h_cnt->trav[1]; stats->leaves = ctx->h_cnt->trav[2];
     }
     return PT_OK;
@@ -870,7 +912,8 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
         }
         ICHK(hipMemcpyAsync(d_o, ho.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
         ICHK(hipMemcpyAsync(d_d, hd.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        rc = launch_extend(ctx, d_o, d_d, nullptr, (uint32_t)m, (uint32_t)m, d_id, d_t);
+        rc = launch_extend(ctx, ctx->stream, ctx->cnt, false, &ctx->gstk, &ctx->gstk_threads, d_o, d_d, (uint32_t)m,
+                           (uint32_t)m, d_id, d_t);
         if (rc != PT_OK) { cleanup(); return rc; }
         hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, m)), dim3(kBlock), 0, ctx->stream, ctx->sc, d_o, d_d, d_id, d_t,
                            (uint32_t)m, d_h);
@@ -988,82 +1031,123 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         ctx->slab_bytes = slab_samples * per_sample;
     }
 
-    // path pool: the configured size, but no more slots than a slab has paths (rounded up to whole refill spans)
-    const uint64_t slab_paths = ((uint64_t)npix * slab_samples + 65535) & ~65535ull;
-    const uint32_t P = (uint32_t)std::min<uint64_t>(ctx->pool, slab_paths);
-    int rc = ensure_pool(ctx, P);
-    if (rc != PT_OK) return rc;
-
     pt_stats acc{};
-    size_t ev_used = 0;
+    double ext_ms = 0;
+    std::vector<std::pair<double, double>> ext_spans;    // begin, end of every extend launch, ms after ev_begin
     HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
-    const int gs = stream_grid(ctx, P);
-    const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
-                                                                 ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));
 
     for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
         const uint64_t first = spp_begin + done_samples;
         const uint64_t count = std::min<uint64_t>(slab_samples, spp_count - done_samples);
-        const uint64_t total = (uint64_t)npix * count;
 
-        Counters init{};
-        init.total_samples = total;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->cnt, &init, sizeof init, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));   // init is a stack object
-
-        const uint64_t min_iters = (total + P - 1) / P;
-        uint64_t it = 0;
-        bool done = false;
-        int cur = 0;       // buffer holding the extended rays
-        while (!done) {
-            PathBuf A = ctx->buf[cur], B = ctx->buf[cur ^ 1];
-            if (it > 0)
-                hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, st, ctx->sc, A, B, ctx->cnt, ctx->slab,
-                                   (uint32_t)first, npix, s0, s1);
-            hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, st, ctx->sc, B, ctx->cnt, P, W, H, (uint32_t)first, s0,
-                               s1, ctx->slab);
-            hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, st, ctx->cnt, P);
-            if (ctx->time_extend) {
-                while (ctx->events.size() < ev_used + 2) {
-                    hipEvent_t ev;
-                    HIPCHK(ctx, hipEventCreate(&ev));
-                    ctx->events.push_back(ev);
-                }
-                HIPCHK(ctx, hipEventRecord(ctx->events[ev_used], st));
-            }
-            rc = launch_extend(ctx, B.o, B.d, ctx->cnt, 0, P, B.hid, B.t);
+        // The slab's samples are split over the lanes.  Each lane is a complete wavefront loop on its own stream, so
+        // one lane's traversal kernel (bound by record fetches through the caches) runs beside another lane's bounce
+        // and generate kernels (bound by streaming state through HBM).  Measured on the headline frame, 1 / 2 / 3 / 4
+        // lanes: 334 / 309 / 305 / 324 ms; on an eighth of its samples (one rank of eight): 43.6 / 41.2 / 39.7 ms.  Which lane renders a sample does not change its slab entry, so the film does not depend on
+        // the lane count.
+        const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
+        for (int k = 0; k < nl; k++) {
+            Lane &ln = ctx->lanes[k];
+            const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
+            ln.first = first + b;
+            ln.count = e - b;
+            ln.total = (uint64_t)npix * ln.count;
+            ln.slab = ctx->slab + (size_t)b * npix;
+            // path pool: the lane's share of the configured size, but no more slots than it has paths
+            const uint64_t want = (ln.total + 65535) & ~65535ull;
+            ln.P = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1024u, ctx->pool / (uint32_t)nl), want);
+            int rc = ensure_pool(ctx, ln, ln.P);
             if (rc != PT_OK) return rc;
-            if (ctx->time_extend) {
-                HIPCHK(ctx, hipEventRecord(ctx->events[ev_used + 1], st));
-                ev_used += 2;
-            }
-            cur ^= 1;
-            it++;
-            if (it >= min_iters) {
-                // poll the device counters two iterations behind the launch front
-                const int slot = (int)(it & 3);
-                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[slot], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipEventRecord(ctx->poll_ev[slot], st));
-                if (it >= min_iters + 2) {
-                    const int old = (int)((it - 2) & 3);
-                    HIPCHK(ctx, hipEventSynchronize(ctx->poll_ev[old]));
-                    const Counters &c = ctx->h_cnt[old];
-                    if (c.n_in == 0 && c.next_sample >= c.total_samples) done = true;
+            ln.min_iters = (ln.total + ln.P - 1) / ln.P;
+            ln.it = 0;
+            ln.cur = 0;
+            ln.ev_used = 0;
+            ln.done = false;
+            Counters &init = ln.h_cnt[4];
+            init = Counters{};
+            init.total_samples = ln.total;
+            HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_slab_free, 0));     // the previous slab has been reduced
+            HIPCHK(ctx, hipMemcpyAsync(ln.cnt, &init, sizeof init, hipMemcpyHostToDevice, ln.stream));
+        }
+
+        for (int live = nl; live > 0;) {
+            for (int k = 0; k < nl; k++) {
+                Lane &ln = ctx->lanes[k];
+                if (ln.done) continue;
+                hipStream_t ls = ln.stream;
+                const uint32_t P = ln.P;
+                PathBuf A = ln.buf[ln.cur], B = ln.buf[ln.cur ^ 1];
+                const int gs = stream_grid(ctx, P);
+                const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
+                                                                             ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
+                if (ln.it > 0)
+                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
+                                       (uint32_t)ln.first, npix, s0, s1);
+                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
+                                   s0, s1, ln.slab);
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, P);
+                if (ctx->time_extend) {
+                    while (ln.events.size() < ln.ev_used + 2) {
+                        hipEvent_t ev;
+                        HIPCHK(ctx, hipEventCreate(&ev));
+                        ln.events.push_back(ev);
+                    }
+                    HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used], ls));
+                }
+                int rc = launch_extend(ctx, ls, ln.cnt, true, &ln.gstk, &ln.gstk_threads, B.o, B.d, 0, P, B.hid, B.t);
+                if (rc != PT_OK) return rc;
+                if (ctx->time_extend) {
+                    HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used + 1], ls));
+                    ln.ev_used += 2;
+                }
+                ln.cur ^= 1;
+                ln.it++;
+                if (ln.it >= ln.min_iters) {
+                    // poll the device counters two iterations behind the launch front
+                    const int slot = (int)(ln.it & 3);
+                    HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[slot], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ls));
+                    HIPCHK(ctx, hipEventRecord(ln.poll_ev[slot], ls));
+                    if (ln.it >= ln.min_iters + 2) {
+                        const int old = (int)((ln.it - 2) & 3);
+                        HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
+                        const Counters &c = ln.h_cnt[old];
+                        if (c.n_in == 0 && c.next_sample >= c.total_samples) {
+                            ln.done = true;
+                            live--;
+                        }
+                    }
                 }
             }
         }
-        // every path of this slab has ended and stored its contribution: fold the slab into the film
+        // every path of this slab has ended and its entry holds what it contributes: fold the slab into the film
+        for (int k = 0; k < nl; k++) {
+            Lane &ln = ctx->lanes[k];
+            HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[0], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ln.stream));
+            HIPCHK(ctx, hipEventRecord(ln.ev_done, ln.stream));
+            HIPCHK(ctx, hipStreamWaitEvent(st, ln.ev_done, 0));
+        }
         hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count, npix,
                            (float)spp_total, ctx->film);
-        HIPCHK(ctx, hipMemcpyAsync(&ctx->h_cnt[0], ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, hipGetLastError());
-        const Counters &c = ctx->h_cnt[0];
-        acc.rays += c.rays_total;
-        acc.paths += c.paths_total;
-        acc.iterations += c.iter;
-        acc.extend_launches += c.extend_nonempty;
-        acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
+        for (int k = 0; k < nl; k++) {
+            Lane &ln = ctx->lanes[k];
+            const Counters &c = ln.h_cnt[0];
+            acc.rays += c.rays_total;
+            acc.paths += c.paths_total;
+            acc.iterations += c.iter;
+            acc.extend_launches += c.extend_nonempty;
+            acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
+            for (size_t i = 0; i + 1 < ln.ev_used; i += 2) {
+                float b = 0, e = 0;
+                HIPCHK(ctx, hipEventElapsedTime(&b, ctx->ev_begin, ln.events[i]));
+                HIPCHK(ctx, hipEventElapsedTime(&e, ln.events[i], ln.events[i + 1]));
+                ext_ms += e;
+                ext_spans.push_back({(double)b, (double)b + e});
+            }
+        }
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1071,13 +1155,21 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
         acc.ms_total = ms;
-        double ext = 0;
-        for (size_t i = 0; i + 1 < ev_used; i += 2) {
-            float e = 0;
-            HIPCHK(ctx, hipEventElapsedTime(&e, ctx->events[i], ctx->events[i + 1]));
-            ext += e;
+        acc.ms_extend = ext_ms;
+        // length of the union of the extend launches' time spans
+        std::sort(ext_spans.begin(), ext_spans.end());
+        double busy = 0, cur_b = 0, cur_e = -1;
+        for (const auto &sp : ext_spans) {
+            if (sp.first > cur_e) {
+                if (cur_e > cur_b) busy += cur_e - cur_b;
+                cur_b = sp.first;
+                cur_e = sp.second;
+            } else {
+                cur_e = std::max(cur_e, sp.second);
+            }
         }
-        acc.ms_extend = ext;
+        if (cur_e > cur_b) busy += cur_e - cur_b;
+        acc.ms_extend_busy = busy;
         *stats = acc;
     }
     return PT_OK;

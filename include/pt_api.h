@@ -107,6 +107,8 @@ typedef struct {
     uint64_t nodes;             /* traversal counters; filled only when PT_OPT_COUNT_TRAVERSAL is set */
     uint64_t tris;
     uint64_t leaves;
+    double ms_extend_busy;      /* time during which at least one extend launch was running (extend launches of
+                                   different streams overlap, so this is below ms_extend when PT_OPT_STREAMS > 1) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
@@ -119,6 +121,8 @@ typedef struct pt_ctx pt_ctx;
                                        slots refilled; 1: one 64-ray batch per wave step, loop-per-phase traversal */
 #define PT_OPT_TUNE_REFILL_IDLE 6   /* extend tuning: refill a wave's ray slots once this many lanes are empty */
 #define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 26) */
+#define PT_OPT_STREAMS          9   /* wavefront loops run side by side on streams of their own, each rendering a share of
+                                       the samples (1..4, default 3); the film does not depend on it */
 #define PT_OPT_ENV_PACK         8   /* 1 (default): keep environment texels as shared-exponent word + pdf (8 B, tiled)
                                        when that reproduces every texel exactly; 0: always 16 B float texels.
                                        Read by pt_scene_upload. */

@@ -239,6 +239,29 @@ def test_packed_environment_texels_change_nothing(pkg):
     c.close()
 
 
+def test_film_does_not_depend_on_the_stream_count(pkg, ctx):
+    """pt_render runs up to four wavefront loops side by side, each on a share of the samples; which loop renders a
+    sample must not show in the film."""
+    W, H, spp = 96, 64, 7
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    films = []
+    try:
+        for lanes in (1, 2, 3, 4):
+            ctx.set_option(pkg.OPT_STREAMS, lanes)
+            ctx.film_clear()
+            st = ctx.render(0, spp, spp, seed=21)
+            assert st.paths == W * H * spp
+            films.append(ctx.film_download())
+    finally:
+        ctx.set_option(pkg.OPT_STREAMS, 3)
+    for f in films[1:]:
+        assert np.array_equal(f, films[0])
+    with pytest.raises(pkg.PtError):
+        ctx.set_option(pkg.OPT_STREAMS, 5)
+
+
 def test_render_in_several_slabs(pkg, ctx):
     """A contribution slab that holds fewer samples than the call renders: the call proceeds slab after slab and the
     film is the same (per-pixel sums are taken per slab, so equal up to float addition order)."""
