@@ -142,6 +142,27 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 ma
 // 342 / 335 / 341 and 124 / 117 / 121.
 constexpr int kBounceBlock = 512;
 
+struct BounceIn { float4 th, d4, o4; float t; uint32_t hid; };
+
+// the whole state in one batch of loads: a path that ends here wastes 36 of the 56 bytes, but its neighbours in the
+// same cache lines need them anyway and nothing later waits for a second round trip
+__device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, uint32_t n)
+{
+    BounceIn s;
+    s.th = make_float4(0, 0, 0, 0); s.d4 = s.th; s.o4 = s.th;
+    s.t = kFltMax;
+    s.hid = PT_PRIM_MISS;
+    if (i < n) {
+        s.t = A.t[i];
+        s.th = A.thr[i];
+        s.d4 = A.d[i];
+        s.o4 = A.o[i];
+        s.hid = A.hid[i];
+    }
+    return s;
+}
+
+template <bool AHEAD>
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
                                                          uint32_t npix, uint32_t seed0, uint32_t seed1)
@@ -151,23 +172,27 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
     __shared__ uint32_t s_base[2];
     const uint32_t n = cnt->n_in;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t stride = gridDim.x * kBounceBlock;
     int par = 0;
+    BounceIn nxt;
+    if (AHEAD) nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n);
     // the trip count is the same for every thread of a block (barriers inside)
-    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += gridDim.x * kBounceBlock, par ^= 1) {
+    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
-        bool alive = false;
-        float4 th = make_float4(0, 0, 0, 0), d4 = th, o4 = th;
-        float t = kFltMax;
-        uint32_t hid = PT_PRIM_MISS;
-        if (i < n) {
-            // the whole state in one batch of loads: a path that ends here wastes 36 of the 56 bytes, but its neighbours
-            // in the same cache lines need them anyway and nothing below waits for a second round trip
-            t = A.t[i];
-            th = A.thr[i];
-            d4 = A.d[i];
-            o4 = A.o[i];
-            hid = A.hid[i];
+        BounceIn in;
+        if (AHEAD) {
+            // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming
+            // loads of one batch overlap the gathers of the one before
+            in = nxt;
+            nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u);
+        } else {
+            in = bounce_load(A, i, n);
         }
+        bool alive = false;
+        float4 th = in.th;
+        const float4 d4 = in.d4, o4 = in.o4;
+        const float t = in.t;
+        const uint32_t hid = in.hid;
         const uint32_t sk = __float_as_uint(th.w);
         const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
         const uint32_t pixel = __float_as_uint(d4.w);
@@ -374,6 +399,7 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
+    bool bounce_ahead = true;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -664,6 +690,7 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
+    case 10: ctx->bounce_ahead = value != 0; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1082,8 +1109,14 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
                                                                              ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
                 if (ln.it > 0)
-                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
-                                       (uint32_t)ln.first, npix, s0, s1);
+                {
+                    if (ctx->bounce_ahead)
+                        hipLaunchKernelGGL(k_bounce<true>, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
+                                           (uint32_t)ln.first, npix, s0, s1);
+                    else
+                        hipLaunchKernelGGL(k_bounce<false>, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
+                                           (uint32_t)ln.first, npix, s0, s1);
+                }
                 hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
                                    s0, s1, ln.slab);
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, P);
