@@ -392,7 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    bool align_leaves = true;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -683,7 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->align_leaves = value != 0; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -728,14 +726,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                     continue;
                 }
                 uint64_t a = (uint64_t)(uint32_t)~ch[c];
-                if (ctx->align_leaves && ((recs.size() / 4) & 1u)) {
-                    // start every leaf on an even record, i.e. on a 128 B line: a two-triangle leaf is then one line fill
-                    for (int r = 0; r < 3; r++) recs.push_back(make_float4(0, 0, 0, 0));
-                    float4 meta = make_float4(0, 0, 0, 0);
-                    uint32_t m[2] = {PT_PRIM_MISS, 3u};
-                    std::memcpy(&meta, m, 8);
-                    recs.push_back(meta);
-                }
                 const uint64_t first = recs.size() / 4;
                 uint64_t count = 0;
                 // the reference's leaf loop stops at the first float4 whose x carries the bits 0x80000000
