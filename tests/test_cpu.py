@@ -359,3 +359,16 @@ def test_two_rank_film_reduce_gloo(tmp_path):
     scene = S.spheres_scene(pkg, 48, 32)
     want, _ = O.render(S.as_oracle_desc(scene), 48, 32, 0, 6, 6, seed=4)
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def test_oracle_film_matches_frozen_fixture(pkg):
+    """The oracle's film of the knot scene equals the frozen one (tests/golden/film_knot.npz, written by
+    tools/make_golden_film.py): scene construction, shading restatement and random streams have not drifted.
+    libm's sin/cos/atan2/acos/pow are the only platform dependence, hence the 1e-6 relative slack."""
+    g = np.load(os.path.join(S.GOLDEN, "film_knot.npz"))
+    W, H, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    scene = S.knot_scene(pkg, W, H)
+    film, st = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=seed)
+    assert st.paths == W * H * spp == int(g["paths"])
+    assert st.rays == int(g["rays"])
+    assert np.allclose(film, g["film"], rtol=1e-6, atol=1e-7)

@@ -162,6 +162,21 @@ def test_render_matches_oracle(pkg, ctx, name):
     assert rmse <= 0.25 * rmse_noise, "tone-mapped RMSE %g vs noise %g" % (rmse, rmse_noise)
 
 
+def test_render_matches_frozen_film(pkg, ctx):
+    """Same bar as above against the film frozen in tests/golden/film_knot.npz (no oracle run involved)."""
+    g = np.load(os.path.join(GOLDEN, "film_knot.npz"))
+    W, H, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=seed)
+    film = ctx.film_download()
+    assert st.paths == int(g["paths"])
+    assert abs(int(st.rays) - int(g["rays"])) <= 0.002 * int(g["rays"])
+    _, differing = film_metrics(film, g["film"])
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+
+
 def test_converged_render_matches_oracle(pkg, ctx):
     """A small frame taken close to convergence (1024 spp): absolute bar on the tone-mapped image,
     RMSE <= 0.01 of full scale, and relMSE of the linear film <= 1e-3."""
