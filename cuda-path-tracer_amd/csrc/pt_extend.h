@@ -137,7 +137,6 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
                                           float4 r3)
 {
     if (COUNT) R.c_nodes++;
-    if (COUNT && (uint32_t)R.node < sc.top_nodes) R.c_tris++;   // EXPERIMENT: counts top-of-tree visits in the triangle counter
     const int cl = fi(r3.x), cr = fi(r3.y);
     float t0l, t0r;
     const bool hl = hit_aabb<CANON>(R.inv, R.nood, r0.x, r0.y, r0.z, r0.w, r2.x, r2.y, R.t, t0l);
@@ -166,7 +165,7 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
                                          float4 meta)
 {
     const uint32_t flags = __float_as_uint(meta.y);
-    // EXPERIMENT if (COUNT && !(flags & 2u)) R.c_tris++;
+    if (COUNT && !(flags & 2u)) R.c_tris++;
     const f3 o = R.o, d = R.d;
     const float Oz = __fmaf_rn(-o.z, v00.z, __fmaf_rn(-o.y, v00.y, __fmaf_rn(-o.x, v00.x, v00.w)));
     const float Dz = __fmaf_rn(d.z, v00.z, __fmaf_rn(d.y, v00.y, d.x * v00.x));

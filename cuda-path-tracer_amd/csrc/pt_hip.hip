@@ -392,7 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    uint32_t dbg_top = 127;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -683,7 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->dbg_top = (uint32_t)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -778,45 +776,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             if (maxd > (uint32_t)kMaxTreeDepth)
                 return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
         }
-        // Renumber the inner nodes so that the top of the tree, the first kTopNodes nodes in breadth-first order, holds
-        // the records [0, top_nodes): those are the records every ray fetches, and the extend kernel keeps a copy of
-        // them in LDS.  Node numbers are internal to this library (hit ids are triangle records), so any order is fine.
-        uint32_t top_nodes = 0;
-        {
-            std::vector<uint32_t> order;
-            order.reserve(N);
-            std::vector<uint8_t> taken(N, 0);
-            order.push_back(0);
-            taken[0] = 1;
-            for (size_t head = 0; head < order.size() && order.size() < (size_t)kTopNodes; head++) {
-                int32_t ch[2];
-                std::memcpy(ch, &recs[(size_t)order[head] * 4 + 3], 8);
-                for (int c = 0; c < 2 && order.size() < (size_t)kTopNodes; c++)
-                    if ((uint64_t)ch[c] < N && !taken[ch[c]]) {
-                        order.push_back((uint32_t)ch[c]);
-                        taken[ch[c]] = 1;
-                    }
-            }
-            top_nodes = (uint32_t)order.size();
-            for (uint64_t i = 0; i < N; i++)
-                if (!taken[i]) order.push_back((uint32_t)i);
-            std::vector<uint32_t> renum(N);
-            for (uint64_t i = 0; i < N; i++) renum[order[i]] = (uint32_t)i;
-            std::vector<float4> nodes(N * 4);
-            for (uint64_t i = 0; i < N; i++) {
-                std::memcpy(&nodes[i * 4], &recs[(size_t)order[i] * 4], 64);
-                int32_t ch[2];
-                std::memcpy(ch, &nodes[i * 4 + 3], 8);
-                for (int c = 0; c < 2; c++)
-                    if ((uint64_t)ch[c] < N) ch[c] = (int32_t)renum[ch[c]];
-                std::memcpy(&nodes[i * 4 + 3], ch, 8);
-            }
-            std::memcpy(recs.data(), nodes.data(), N * 64);
-        }
         int rc;
         if ((rc = upload(ctx, recs, &sc.recs)) != PT_OK) return rc;
         sc.first_tri = (uint32_t)N;
-        sc.top_nodes = std::min<uint32_t>(top_nodes, ctx->dbg_top);
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
         sc.mesh_type = s->mesh_material_type;
