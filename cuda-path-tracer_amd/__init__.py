@@ -101,6 +101,7 @@ def host_lib():
                                       C.POINTER(Camera)]
         L.pth_tonemap16.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_void_p]
         L.pth_png16_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pth_pfm_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.pth_asset_generate.argtypes = [C.c_char_p, C.c_char_p]
         _host = L
     return _host
@@ -281,6 +282,11 @@ def tonemap16(film, exposure=2.0, gamma=2.2):
 def png16_write(path, rgb16):
     rgb16 = np.ascontiguousarray(rgb16, dtype=np.uint16)
     _hcheck(host_lib().pth_png16_write(os.fsencode(path), _ptr(rgb16), rgb16.shape[1], rgb16.shape[0]))
+
+
+def pfm_write(path, film):
+    film = np.ascontiguousarray(film, dtype=np.float32)
+    _hcheck(host_lib().pth_pfm_write(os.fsencode(path), _ptr(film), film.shape[1], film.shape[0]))
 
 
 def asset_generate(kind, path):

@@ -61,6 +61,10 @@ int main(int argc, char **argv)
     std::vector<float> film(width * height * 3);
     check(pt_film_download(ctx, film.data()));
 
+    if (const char *e = std::getenv("PT_PFM"))          // PT_PFM=1: also dump the linear film as image_file.pfm
+        if (e[0] == '1' && pth_pfm_write((image_file + ".pfm").c_str(), film.data(), (uint32_t)width, (uint32_t)height) != 0)
+            std::cerr << "Error writing PFM: " << pth_last_error() << "\n";
+
     std::cout << "Saving image...\n";
     t1 = std::chrono::high_resolution_clock::now();
     std::vector<uint16_t> rgb16(width * height * 3);

@@ -368,6 +368,19 @@ int pth_png16_write(const char *path, const uint16_t *rgb, uint32_t w, uint32_t 
     return png16_write(path, rgb, w, h);
 }
 
+int pth_pfm_write(const char *path, const float *film_rgb, uint32_t w, uint32_t h)
+{
+    if (!path || !film_rgb || w == 0 || h == 0) return set_error("pth_pfm_write: bad argument");
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return set_error("%s: cannot open for writing", path);
+    std::fprintf(f, "PF\n%u %u\n-1.0\n", w, h);
+    bool ok = true;
+    for (uint32_t row = h; row-- > 0 && ok;)           // the film's row 0 is the top, a PFM starts at the bottom
+        ok = std::fwrite(film_rgb + (size_t)row * w * 3, sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;
+    ok = std::fclose(f) == 0 && ok;
+    return ok ? 0 : set_error("%s: write failed", path);
+}
+
 int pth_asset_generate(const char *kind, const char *path)
 {
     if (!kind || !path) return set_error("pth_asset_generate: bad argument");

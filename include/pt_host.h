@@ -67,6 +67,9 @@ void pth_camera_make(const float pos[3], const float look_at[3], float fov, floa
 void pth_tonemap16(const float *film_rgb, uint64_t npixels, float exposure, float gamma, uint16_t *out_rgb);
 /* 16-bit RGB PNG (reference src/image.cpp:35-50 writes the same pixel format through lodepng). */
 int  pth_png16_write(const char *path, const uint16_t *rgb, uint32_t w, uint32_t h);
+/* The linear film as a little-endian colour PFM ("PF", rows bottom to top): the exact floats, for parity tooling.
+ * No reference counterpart (the reference only writes the tone-mapped PNG). */
+int  pth_pfm_write(const char *path, const float *film_rgb, uint32_t w, uint32_t h);
 
 /* ---- procedural stand-ins for assets the reference repository does not ship -------------------------------- */
 /* kind: "studio.hdr", "sunset.hdr", "forest.hdr" (2048x1024 lat-long maps) or "dragon.obj" (868,352-triangle

@@ -372,3 +372,15 @@ def test_oracle_film_matches_frozen_fixture(pkg):
     assert st.paths == W * H * spp == int(g["paths"])
     assert st.rays == int(g["rays"])
     assert np.allclose(film, g["film"], rtol=1e-6, atol=1e-7)
+
+
+def test_pfm_writer_keeps_the_exact_floats(pkg, tmp_path):
+    rng = np.random.default_rng(5)
+    film = rng.random((7, 5, 3), dtype=np.float32) * 40
+    path = str(tmp_path / "f.pfm")
+    pkg.pfm_write(path, film)
+    raw = open(path, "rb").read()
+    header = b"PF\n5 7\n-1.0\n"
+    assert raw.startswith(header)
+    back = np.frombuffer(raw[len(header):], dtype="<f4").reshape(7, 5, 3)[::-1]
+    assert np.array_equal(back, film)
