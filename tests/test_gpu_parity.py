@@ -358,6 +358,14 @@ def test_error_paths(pkg):
         c.set_option(pkg.OPT_POOL_SIZE, 8)
     with pytest.raises(pkg.PtError):
         pkg.Context(99)
+    # an empty sample range is a no-op; a single sample uses one stream
+    st = c.render(2, 0, 4)
+    assert st.paths == 0 and st.rays == 0 and not c.film_download().any()
+    st = c.render(2, 1, 4)
+    assert st.paths == 48 * 32
+    one = c.film_download()
+    o, _ = O.render(S.as_oracle_desc(scene), 48, 32, 2, 1, 4, seed=0)
+    assert film_metrics(one, o)[1] <= MAX_FLIPPED_PATH_RATE * 4
     c.close()
 
 
