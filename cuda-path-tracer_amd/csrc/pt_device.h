@@ -47,6 +47,26 @@ __device__ __forceinline__ f3 reflect3(f3 i, f3 n)
 __device__ __forceinline__ int fi(float f) { return __float_as_int(f); }
 __device__ __forceinline__ float fl(int i) { return __int_as_float(i); }
 
+// ---- streaming accesses ------------------------------------------------------------------------------------------
+// Path state, hit records and slab entries are read or written once per kernel and never again before other data has
+// passed through the caches; marking those accesses non-temporal keeps them from pushing the BVH's upper levels and
+// the environment map out of the 4 MB L2 of each XCD.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4 *p)
+{
+    const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float4 *p, float4 v)
+{
+    v4f_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<v4f_t *>(p));
+}
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 // ---- scene as the kernels see it ----------------------------------------------------------------------------
 struct DPlane { float4 pos; float4 nrm; float4 mat; uint32_t type; uint32_t pad[3]; };    // 64 B
 struct DSphere { float4 pos_r; float4 mat; uint32_t type; uint32_t pad[3]; };            // 48 B

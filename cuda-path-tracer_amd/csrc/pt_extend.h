@@ -126,8 +126,8 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
 
 __device__ __forceinline__ void ray_retire(const RayState &R, uint32_t ray, uint32_t *hid_out, float *t_out)
 {
-    hid_out[ray] = R.hid;
-    t_out[ray] = R.t;
+    st_stream(hid_out + ray, R.hid);
+    st_stream(t_out + ray, R.t);
 }
 
 // One inner-node step (reference src/bvh.cuh:141-168): test both child boxes, descend into the nearer hit child
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             if (want && rank < take) {
                 pray = next + rank;
-                po = a.ro[pray];
-                pd = a.rd[pray];
+                po = ld_stream(a.ro + pray);
+                pd = ld_stream(a.rd + pray);
                 want = false;
             }
             next += take;
