@@ -146,7 +146,6 @@ struct BounceIn { float4 th, d4, o4; float t; uint32_t hid; };
 
 // the whole state in one batch of loads: a path that ends here wastes 36 of the 56 bytes, but its neighbours in the
 // same cache lines need them anyway and nothing later waits for a second round trip
-template <bool NT>
 __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, uint32_t n)
 {
     BounceIn s;
@@ -154,16 +153,15 @@ __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, ui
     s.t = kFltMax;
     s.hid = PT_PRIM_MISS;
     if (i < n) {
-        s.t = NT ? ld_stream(A.t + i) : A.t[i];
-        s.th = NT ? ld_stream(A.thr + i) : A.thr[i];
-        s.d4 = NT ? ld_stream(A.d + i) : A.d[i];
-        s.o4 = NT ? ld_stream(A.o + i) : A.o[i];
-        s.hid = NT ? ld_stream(A.hid + i) : A.hid[i];
+        s.t = ld_stream(A.t + i);
+        s.th = ld_stream(A.thr + i);
+        s.d4 = ld_stream(A.d + i);
+        s.o4 = ld_stream(A.o + i);
+        s.hid = ld_stream(A.hid + i);
     }
     return s;
 }
 
-template <bool NT>
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
                                                          uint32_t npix, uint32_t seed0, uint32_t seed1)
@@ -175,14 +173,14 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * kBounceBlock;
     int par = 0;
-    BounceIn nxt = bounce_load<NT>(A, blockIdx.x * kBounceBlock + threadIdx.x, n);
+    BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n);
     // the trip count is the same for every thread of a block (barriers inside)
     for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
         // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming loads
         // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
         const BounceIn in = nxt;
-        nxt = bounce_load<NT>(A, i + stride, (uint64_t)first + stride < n ? n : 0u);
+        nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u);
         bool alive = false;
         float4 th = in.th;
         const float4 d4 = in.d4, o4 = in.o4;
@@ -199,9 +197,7 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
                 const float p = fmaxf(th.x, fmaxf(th.y, th.z));
                 if (rng.next() > p) {
                     alive = false;
-                    float4 *entry = slab + (size_t)(sample - slab_first_sample) * npix + pixel;
-                    if (NT) st_stream(entry, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                    else *entry = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 } else {
                     const float ip = 1 / p;
                     th.x *= ip; th.y *= ip; th.z *= ip;
@@ -236,24 +232,16 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
             else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
-            float4 *entry = slab + (size_t)(sample - slab_first_sample) * npix + pixel;
-            if (NT) st_stream(entry, escape_value(th, e));
-            else *entry = escape_value(th, e);
+            st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
             th.w = __uint_as_float(sample | ((k + 1) << 27));
         }
         if (threadIdx.x == 0) s_base[par] = claimed;
         __syncthreads();
         if (alive) {
             const uint32_t dst = s_base[par] + r;
-            if (NT) {
-                st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
-                st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
-                st_stream(B.thr + dst, th);
-            } else {
-                B.o[dst] = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
-                B.d[dst] = make_float4(out.x, out.y, out.z, d4.w);
-                B.thr[dst] = th;
-            }
+            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
+            st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
+            st_stream(B.thr + dst, th);
         }
     }
 }
@@ -404,7 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    bool nt = true;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -695,7 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->nt = value != 0; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1114,14 +1100,8 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
                                                                              ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
                 if (ln.it > 0)
-                {
-                    if (ctx->nt)
-                        hipLaunchKernelGGL(k_bounce<true>, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
-                                           (uint32_t)ln.first, npix, s0, s1);
-                    else
-                        hipLaunchKernelGGL(k_bounce<false>, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
-                                           (uint32_t)ln.first, npix, s0, s1);
-                }
+                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
+                                       (uint32_t)ln.first, npix, s0, s1);
                 hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
                                    s0, s1, ln.slab);
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, P);
