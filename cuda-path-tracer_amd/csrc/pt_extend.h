@@ -36,7 +36,6 @@ struct ExtendArgs {
     float *t_out;              // hit distance, FLT_MAX on a miss
     unsigned long long *cnt3;  // nodes, triangles, leaves (COUNT only)
     int refill_idle;
-    int tri_nt;
     int lds_slots;             // traversal stack slots per lane kept in LDS
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
 };
@@ -241,16 +240,12 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
 
 // ---- persistent single-step traversal ---------------------------------------------------------------------------------
 template <bool COUNT, bool CANON, class STK>
-__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk, int tri_nt)
+__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
     if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
-    float4 r0, r1, r2, r3;
-    if (tri_nt && (uint32_t)R.node >= sc.first_tri) {
-        r0 = ld_stream(p); r1 = ld_stream(p + 1); r2 = ld_stream(p + 2); r3 = ld_stream(p + 3);
-    } else {
-        r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
-    }
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
@@ -330,8 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight, so nothing fetched ahead either
         }
-        if (canon) stream_step<COUNT, true>(sc, R, stk, a.tri_nt);
-        else stream_step<COUNT, false>(sc, R, stk, a.tri_nt);
+        if (canon) stream_step<COUNT, true>(sc, R, stk);
+        else stream_step<COUNT, false>(sc, R, stk);
     }
     flush_counts<COUNT>(R, a.cnt3);
 }

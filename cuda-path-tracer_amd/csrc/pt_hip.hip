@@ -392,7 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    int tri_nt = 1;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -549,7 +548,6 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.hid_out = hid; a.t_out = t;
     a.cnt3 = &cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
-    a.tri_nt = ctx->tri_nt;
     a.lds_slots = lds_slots;
     a.gstk = *gstk;
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
@@ -684,7 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->tri_nt = (int)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
