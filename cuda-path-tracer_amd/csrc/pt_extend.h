@@ -244,8 +244,8 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
 {
     if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
-    const float4 r0 = ld_stream(p), r1 = ld_stream(p + 1), r2 = ld_stream(p + 2);
-    float4 r3 = ld_stream(p + 3);
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
