@@ -118,8 +118,8 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
         n = (p - xyz(pr)) / pr.w;
     } else {
         const float4 *rec = sc.recs + (size_t)hid * 4;
-        n = cross3(xyz(ld_stream(rec + 1)), xyz(ld_stream(rec + 2)));
-        prim = __float_as_uint(ld_stream(rec + 3).x);
+        n = cross3(xyz(rec[1]), xyz(rec[2]));
+        prim = __float_as_uint(rec[3].x);
     }
     return normalize3(n);
 }
