@@ -392,7 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    bool uncached_state = false;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -455,23 +454,17 @@ static void free_pool(Lane &ln)
 }
 
 // Grow-only: the lane's buffers hold at least `slots` paths afterwards.
-static hipError_t stream_malloc(pt_ctx *ctx, void **p, size_t bytes)
-{
-    if (ctx->uncached_state) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
-    return hipMalloc(p, bytes);
-}
-
 static int ensure_pool(pt_ctx *ctx, Lane &ln, uint32_t slots)
 {
     if (ln.pool_alloc >= slots) return PT_OK;
     free_pool(ln);
     const size_t P = slots;
     for (auto &b : ln.buf) {
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&b.o, P * sizeof(float4)));
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&b.d, P * sizeof(float4)));
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&b.thr, P * sizeof(float4)));
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&b.hid, P * sizeof(uint32_t)));
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&b.t, P * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&b.o, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.d, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.thr, P * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&b.hid, P * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
     }
     ln.pool_alloc = slots;
     return PT_OK;
@@ -689,7 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->uncached_state = value != 0; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1053,7 +1045,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
     slab_samples = std::min<uint64_t>(slab_samples, std::max<uint64_t>(1, spp_count));
     if (ctx->slab_bytes < slab_samples * per_sample) {
         if (ctx->slab) { (void)hipFree(ctx->slab); ctx->slab = nullptr; ctx->slab_bytes = 0; }
-        HIPCHK(ctx, stream_malloc(ctx, (void **)&ctx->slab, slab_samples * per_sample));
+        HIPCHK(ctx, hipMalloc(&ctx->slab, slab_samples * per_sample));
         ctx->slab_bytes = slab_samples * per_sample;
     }
 
