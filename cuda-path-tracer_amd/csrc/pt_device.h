@@ -17,7 +17,6 @@ constexpr uint32_t kMinDepth = 3;                                // reference sr
 constexpr uint32_t kMaxDepth = 16;                               // reference src/render.cu:9
 constexpr float kFltMax = 3.402823466e+38f;
 constexpr int kSentinel = 0x76543210;                            // bottom-of-stack marker, never a node index
-constexpr int kTopNodes = 64;                                    // top-of-tree nodes renumbered to the front
 constexpr int kMaxTreeDepth = 63;                                // reference src/bvh.cuh:12 (64 entries, one sentinel)
 
 struct f3 { float x, y, z; };
@@ -79,7 +78,6 @@ struct DScene {
     const float4 *recs;
     uint32_t first_tri;
     uint32_t stack_slots;    // traversal stack slots a ray can need: tree depth + 1
-    uint32_t top_nodes;      // records [0, top_nodes) are the top of the tree in breadth-first order
     const DPlane *planes;
     const DSphere *spheres;
     uint32_t num_planes, num_spheres, has_bvh, mesh_type;

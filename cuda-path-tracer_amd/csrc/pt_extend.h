@@ -37,7 +37,6 @@ struct ExtendArgs {
     unsigned long long *cnt3;  // nodes, triangles, leaves (COUNT only)
     int refill_idle;
     int lds_slots;             // traversal stack slots per lane kept in LDS
-    uint32_t cache_nodes;      // records [0, cache_nodes) are copied to LDS behind the stacks (stream kernel)
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
 };
 
@@ -240,21 +239,13 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
 }
 
 // ---- persistent single-step traversal ---------------------------------------------------------------------------------
-template <bool COUNT, bool CANON, bool CACHE, class STK>
-__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk, const float4 *cache,
-                                            uint32_t cache_nodes)
+template <bool COUNT, bool CANON, class STK>
+__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
     if (R.node == kSentinel) return;
-    float4 r0, r1, r2, r3;
-    if (CACHE && (uint32_t)R.node < cache_nodes) {
-        // the top of the tree is read from the block's LDS copy: these are the records every ray needs, and reading
-        // them here takes them off the texture-address unit, which is what the kernel is short of
-        const float4 *q = cache + (size_t)R.node * 4;
-        r0 = q[0]; r1 = q[1]; r2 = q[2]; r3 = q[3];
-    } else {
-        const float4 *p = sc.recs + (size_t)R.node * 4;
-        r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
-    }
+    const float4 *p = sc.recs + (size_t)R.node * 4;
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
@@ -262,16 +253,10 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
 }
 
-template <bool OVERFLOW, bool COUNT, bool CACHE>
+template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs a)
 {
     const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
-    const float4 *cache = reinterpret_cast<const float4 *>(g_stack_lds + (size_t)a.lds_slots * kBlock);
-    if (CACHE) {
-        float4 *w = reinterpret_cast<float4 *>(g_stack_lds + (size_t)a.lds_slots * kBlock);
-        for (uint32_t i = threadIdx.x; i < a.cache_nodes * 4; i += kBlock) w[i] = sc.recs[i];
-        __syncthreads();
-    }
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
     const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
     // wave-uniform cursor over this wave's chunks of the ray buffer
@@ -340,8 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight, so nothing fetched ahead either
         }
-        if (canon) stream_step<COUNT, true, CACHE>(sc, R, stk, cache, a.cache_nodes);
-        else stream_step<COUNT, false, CACHE>(sc, R, stk, cache, a.cache_nodes);
+        if (canon) stream_step<COUNT, true>(sc, R, stk);
+        else stream_step<COUNT, false>(sc, R, stk);
     }
     flush_counts<COUNT>(R, a.cnt3);
 }

@@ -392,9 +392,6 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
-    bool tree_cache = true;
-    uint32_t dbg_cache_cap = 64;
-    int dbg_blocks = 8;
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -532,9 +529,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
     const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
     const bool overflow = need > (uint32_t)lds_slots;
-    const uint32_t cache_nodes = (ctx->tree_cache && ctx->extend_mode == 2 && ctx->sc.has_bvh) ? std::min<uint32_t>(ctx->sc.top_nodes, ctx->dbg_cache_cap) : 0;
-    const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int) + (size_t)cache_nodes * 64;
-    const int per_cu = std::max(1, std::min(ctx->dbg_blocks, (int)(160 * 1024 / shmem)));
+    const int per_cu = std::max(1, std::min(8, 160 / lds_slots));
     const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     const uint64_t want = ((uint64_t)n_upper + kBlock - 1) / kBlock;
     const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
@@ -554,23 +549,18 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.cnt3 = &cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
-    a.cache_nodes = cache_nodes;
     a.gstk = *gstk;
+    const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
 #define PT_LAUNCH(K, OV, CT) hipLaunchKernelGGL((K<OV, CT>), g, b, shmem, stream, ctx->sc, a)
-#define PT_LAUNCH3(K, OV, CT, CA) hipLaunchKernelGGL((K<OV, CT, CA>), g, b, shmem, stream, ctx->sc, a)
     if (ctx->extend_mode == 1) {
         if (overflow) { if (count) PT_LAUNCH(k_extend_batch, true, true); else PT_LAUNCH(k_extend_batch, true, false); }
         else { if (count) PT_LAUNCH(k_extend_batch, false, true); else PT_LAUNCH(k_extend_batch, false, false); }
-    } else if (cache_nodes) {
-        if (overflow) { if (count) PT_LAUNCH3(k_extend_stream, true, true, true); else PT_LAUNCH3(k_extend_stream, true, false, true); }
-        else { if (count) PT_LAUNCH3(k_extend_stream, false, true, true); else PT_LAUNCH3(k_extend_stream, false, false, true); }
     } else {
-        if (overflow) { if (count) PT_LAUNCH3(k_extend_stream, true, true, false); else PT_LAUNCH3(k_extend_stream, true, false, false); }
-        else { if (count) PT_LAUNCH3(k_extend_stream, false, true, false); else PT_LAUNCH3(k_extend_stream, false, false, false); }
+        if (overflow) { if (count) PT_LAUNCH(k_extend_stream, true, true); else PT_LAUNCH(k_extend_stream, true, false); }
+        else { if (count) PT_LAUNCH(k_extend_stream, false, true); else PT_LAUNCH(k_extend_stream, false, false); }
     }
-#undef PT_LAUNCH3
 #undef PT_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return PT_OK;
@@ -692,9 +682,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
         return PT_OK;
-    case 10: ctx->tree_cache = value != 0; return PT_OK;
-    case 11: ctx->dbg_blocks = (int)value; return PT_OK;
-    case 12: ctx->dbg_cache_cap = (uint32_t)value; return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -789,45 +776,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             if (maxd > (uint32_t)kMaxTreeDepth)
                 return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
         }
-        // Renumber the inner nodes so that the top of the tree, the first kTopNodes nodes in breadth-first order, holds
-        // the records [0, top_nodes): those are the records every ray fetches, and the extend kernel keeps a copy of
-        // them in LDS.  Node numbers are internal to this library (hit ids are triangle records), so any order is fine.
-        uint32_t top_nodes = 0;
-        {
-            std::vector<uint32_t> order;
-            order.reserve(N);
-            std::vector<uint8_t> taken(N, 0);
-            order.push_back(0);
-            taken[0] = 1;
-            for (size_t head = 0; head < order.size() && order.size() < (size_t)kTopNodes; head++) {
-                int32_t ch[2];
-                std::memcpy(ch, &recs[(size_t)order[head] * 4 + 3], 8);
-                for (int c = 0; c < 2 && order.size() < (size_t)kTopNodes; c++)
-                    if ((uint64_t)ch[c] < N && !taken[ch[c]]) {
-                        order.push_back((uint32_t)ch[c]);
-                        taken[ch[c]] = 1;
-                    }
-            }
-            top_nodes = (uint32_t)order.size();
-            for (uint64_t i = 0; i < N; i++)
-                if (!taken[i]) order.push_back((uint32_t)i);
-            std::vector<uint32_t> renum(N);
-            for (uint64_t i = 0; i < N; i++) renum[order[i]] = (uint32_t)i;
-            std::vector<float4> nodes(N * 4);
-            for (uint64_t i = 0; i < N; i++) {
-                std::memcpy(&nodes[i * 4], &recs[(size_t)order[i] * 4], 64);
-                int32_t ch[2];
-                std::memcpy(ch, &nodes[i * 4 + 3], 8);
-                for (int c = 0; c < 2; c++)
-                    if ((uint64_t)ch[c] < N) ch[c] = (int32_t)renum[ch[c]];
-                std::memcpy(&nodes[i * 4 + 3], ch, 8);
-            }
-            std::memcpy(recs.data(), nodes.data(), N * 64);
-        }
         int rc;
         if ((rc = upload(ctx, recs, &sc.recs)) != PT_OK) return rc;
         sc.first_tri = (uint32_t)N;
-        sc.top_nodes = top_nodes;
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
         sc.mesh_type = s->mesh_material_type;
