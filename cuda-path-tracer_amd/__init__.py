@@ -111,7 +111,8 @@ def hip_lib():
     """The device library.  Raises if it is missing: there is no fallback path."""
     global _hip
     if _hip is None:
-        path = os.path.join(PKG_DIR, "libpt_hip.so")
+        # PT_HIP_LIB: another build of the library (A/B runs of compile-time variants)
+        path = os.environ.get("PT_HIP_LIB") or os.path.join(PKG_DIR, "libpt_hip.so")
         if not os.path.exists(path):
             raise PtError("libpt_hip.so is not built: run `make -C %s`" % PKG_DIR)
         try:

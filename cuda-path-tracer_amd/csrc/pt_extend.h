@@ -21,7 +21,10 @@ namespace ptd {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
-constexpr uint32_t kChunk = 128;           // rays per chunk; chunk c belongs to wave c mod #waves
+#ifndef PT_KCHUNK
+#define PT_KCHUNK 128
+#endif
+constexpr uint32_t kChunk = PT_KCHUNK;           // rays per chunk; chunk c belongs to wave c mod #waves
 // stream kernel: refill once this many lanes have no ray.  Measured on the 868 k-triangle stand-in, 78 M rays per launch
 // (ms per frame): 8 -> 356, 16 -> 342, 24 -> 333, 32 -> 327, 44 -> 320, 56 -> 340.  Idle lanes cost no memory traffic,
 // which is what bounds the kernel; every refill is issue time the wave's live rays stand still for.
@@ -118,8 +121,13 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
         n = (p - xyz(pr)) / pr.w;
     } else {
         const float4 *rec = sc.recs + (size_t)hid * 4;
+#ifdef PT_VARIANT_NT_NORMAL
+        n = cross3(xyz(ld_stream(rec + 1)), xyz(ld_stream(rec + 2)));
+        prim = __float_as_uint(ld_stream(rec + 3).x);
+#else
         n = cross3(xyz(rec[1]), xyz(rec[2]));
         prim = __float_as_uint(rec[3].x);
+#endif
     }
     return normalize3(n);
 }
@@ -244,8 +252,13 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
 {
     if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
+#ifdef PT_VARIANT_NT_RECS
+    const float4 r0 = ld_stream(p), r1 = ld_stream(p + 1), r2 = ld_stream(p + 2);
+    float4 r3 = ld_stream(p + 3);
+#else
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     float4 r3 = p[3];
+#endif
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
@@ -303,25 +316,41 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             m = __ballot(want);
         }
     };
+#ifndef PT_VARIANT_NO_AHEAD
     fetch_ahead();
+#endif
 
     for (;;) {
         const bool idle = R.node == kSentinel;
         const int nidle = __popcll(__ballot(idle));
-        if (nidle == 64 || (nidle >= a.refill_idle && __any(idle && pray != kNoRay))) {
+#ifdef PT_VARIANT_NO_AHEAD
+        const bool can_refill = next < end || ((uint64_t)chunk + nwaves) * kChunk < n;
+#else
+        const bool can_refill = __any(idle && pray != kNoRay);
+#endif
+        if (nidle == 64 || (nidle >= a.refill_idle && can_refill)) {
             // retire finished rays, start the rays fetched ahead, fetch the ones after them
             if (ray != kNoRay && idle) {
                 ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
             }
+#ifdef PT_VARIANT_NO_AHEAD
+            // variant: nothing is kept fetched ahead; the slots that are empty now fetch and start their rays at once
+            if (ray != kNoRay) pray = 0;          // occupied slots ask for nothing
+            else pray = kNoRay;
+            fetch_ahead();
+            if (ray != kNoRay) pray = kNoRay;
+#endif
             if (ray == kNoRay && pray != kNoRay) {
                 ray = pray;
                 pray = kNoRay;
                 ray_begin(sc, R, xyz(po), xyz(pd), stk);
                 degenerate = slab_degenerate(R.d);
             }
+#ifndef PT_VARIANT_NO_AHEAD
             fetch_ahead();
+#endif
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight, so nothing fetched ahead either
         }
