@@ -121,13 +121,8 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
         n = (p - xyz(pr)) / pr.w;
     } else {
         const float4 *rec = sc.recs + (size_t)hid * 4;
-#ifdef PT_VARIANT_NT_NORMAL
-        n = cross3(xyz(ld_stream(rec + 1)), xyz(ld_stream(rec + 2)));
-        prim = __float_as_uint(ld_stream(rec + 3).x);
-#else
         n = cross3(xyz(rec[1]), xyz(rec[2]));
         prim = __float_as_uint(rec[3].x);
-#endif
     }
     return normalize3(n);
 }
@@ -252,13 +247,8 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
 {
     if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
-#ifdef PT_VARIANT_NT_RECS
-    const float4 r0 = ld_stream(p), r1 = ld_stream(p + 1), r2 = ld_stream(p + 2);
-    float4 r3 = ld_stream(p + 3);
-#else
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     float4 r3 = p[3];
-#endif
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
@@ -287,72 +277,39 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     uint32_t ray = kNoRay;
     bool degenerate = false;
     bool canon = false;          // wave-uniform: some ray in flight needs the NaN-rewriting slab test
-
-    // Every lane keeps the NEXT ray it will trace already loaded (origin and direction in registers), so that starting
-    // a ray costs no memory round trip during which the wave's other rays would stand still: the loads are issued when
-    // the previous ray starts and have long arrived when it ends.
-    uint32_t pray = kNoRay;
-    float4 po = make_float4(0, 0, 0, 0), pd = po;
-    auto fetch_ahead = [&]() {
-        bool want = pray == kNoRay;
-        unsigned long long m = __ballot(want);
-        while (m) {
-            if (next >= end) {
-                const uint64_t c2 = (uint64_t)chunk + nwaves;
-                if (c2 * kChunk >= n) break;
-                chunk = (uint32_t)c2;
-                next = chunk * kChunk;
-                end = min(n, next + kChunk);
-            }
-            const uint32_t take = min(end - next, (uint32_t)__popcll(m));
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            if (want && rank < take) {
-                pray = next + rank;
-                po = ld_stream(a.ro + pray);
-                pd = ld_stream(a.rd + pray);
-                want = false;
-            }
-            next += take;
-            m = __ballot(want);
-        }
-    };
-#ifndef PT_VARIANT_NO_AHEAD
-    fetch_ahead();
-#endif
+    bool more_work = true;
 
     for (;;) {
-        const bool idle = R.node == kSentinel;
-        const int nidle = __popcll(__ballot(idle));
-#ifdef PT_VARIANT_NO_AHEAD
-        const bool can_refill = next < end || ((uint64_t)chunk + nwaves) * kChunk < n;
-#else
-        const bool can_refill = __any(idle && pray != kNoRay);
-#endif
-        if (nidle == 64 || (nidle >= a.refill_idle && can_refill)) {
-            // retire finished rays, start the rays fetched ahead, fetch the ones after them
-            if (ray != kNoRay && idle) {
+        const int nidle = __popcll(__ballot(R.node == kSentinel));
+        if (nidle == 64 || (more_work && nidle >= a.refill_idle)) {
+            // retire finished rays, refill their slots
+            if (ray != kNoRay && R.node == kSentinel) {
                 ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
             }
-#ifdef PT_VARIANT_NO_AHEAD
-            // variant: nothing is kept fetched ahead; the slots that are empty now fetch and start their rays at once
-            if (ray != kNoRay) pray = 0;          // occupied slots ask for nothing
-            else pray = kNoRay;
-            fetch_ahead();
-            if (ray != kNoRay) pray = kNoRay;
-#endif
-            if (ray == kNoRay && pray != kNoRay) {
-                ray = pray;
-                pray = kNoRay;
-                ray_begin(sc, R, xyz(po), xyz(pd), stk);
+            const bool empty = ray == kNoRay;
+            const unsigned long long emask = __ballot(empty);
+            if (next >= end) {
+                const uint64_t c2 = (uint64_t)chunk + nwaves;
+                if (c2 * kChunk < n) {
+                    chunk = (uint32_t)c2;
+                    next = chunk * kChunk;
+                    end = min(n, next + kChunk);
+                }
+            }
+            const uint32_t take = min(end - next, (uint32_t)__popcll(emask));
+            const uint32_t rank =
+                __builtin_amdgcn_mbcnt_hi((uint32_t)(emask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emask, 0));
+            if (empty && rank < take) {
+                ray = next + rank;
+                ray_begin(sc, R, xyz(ld_stream(a.ro + ray)), xyz(ld_stream(a.rd + ray)), stk);
                 degenerate = slab_degenerate(R.d);
             }
-#ifndef PT_VARIANT_NO_AHEAD
-            fetch_ahead();
-#endif
+            next += take;
+            more_work = next < end || ((uint64_t)chunk + nwaves) * kChunk < n;
             canon = __any(degenerate);
-            if (!__any(ray != kNoRay)) break;            // nothing in flight, so nothing fetched ahead either
+            if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }
         if (canon) stream_step<COUNT, true>(sc, R, stk);
         else stream_step<COUNT, false>(sc, R, stk);
