@@ -149,10 +149,15 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
     int next = hl ? cl : cr;
     next = right_first ? cr : next;
     const int far_child = right_first ? cl : cr;
+#ifdef PT_VARIANT_PUSH_ALWAYS
+    stk.put(R.sp, far_child);       // the slot above the top is scratch: written always, kept only when both are hit
+    R.sp += both ? 1 : 0;
+#else
     if (both) {
         stk.put(R.sp, far_child);
         R.sp++;
     }
+#endif
     if (!(hl || hr)) {
         R.sp--;
         next = stk.get(R.sp);
@@ -251,7 +256,9 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
+#ifndef PT_VARIANT_NO_PIN
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
+#endif
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
     else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
 }
@@ -311,8 +318,16 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }
-        if (canon) stream_step<COUNT, true>(sc, R, stk);
-        else stream_step<COUNT, false>(sc, R, stk);
+#ifndef PT_STEPS
+#define PT_STEPS 1
+#endif
+        if (canon) {
+#pragma unroll
+            for (int s = 0; s < PT_STEPS; s++) stream_step<COUNT, true>(sc, R, stk);
+        } else {
+#pragma unroll
+            for (int s = 0; s < PT_STEPS; s++) stream_step<COUNT, false>(sc, R, stk);
+        }
     }
     flush_counts<COUNT>(R, a.cnt3);
 }
