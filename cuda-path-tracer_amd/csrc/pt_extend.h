@@ -21,9 +21,14 @@ namespace ptd {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+// PT_KCHUNK / PT_STEPS: compile-time overrides for A/B builds (tools/ab_libs.sh)
 #ifndef PT_KCHUNK
 #define PT_KCHUNK 128
 #endif
+#ifndef PT_STEPS
+#define PT_STEPS 2
+#endif
+constexpr int kStepsPerCheck = PT_STEPS;
 constexpr uint32_t kChunk = PT_KCHUNK;           // rays per chunk; chunk c belongs to wave c mod #waves
 // stream kernel: refill once this many lanes have no ray.  Measured on the 868 k-triangle stand-in, 78 M rays per launch
 // (ms per frame): 8 -> 356, 16 -> 342, 24 -> 333, 32 -> 327, 44 -> 320, 56 -> 340.  Idle lanes cost no memory traffic,
@@ -149,15 +154,10 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
     int next = hl ? cl : cr;
     next = right_first ? cr : next;
     const int far_child = right_first ? cl : cr;
-#ifdef PT_VARIANT_PUSH_ALWAYS
-    stk.put(R.sp, far_child);       // the slot above the top is scratch: written always, kept only when both are hit
-    R.sp += both ? 1 : 0;
-#else
     if (both) {
         stk.put(R.sp, far_child);
         R.sp++;
     }
-#endif
     if (!(hl || hr)) {
         R.sp--;
         next = stk.get(R.sp);
@@ -256,9 +256,7 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
-#ifndef PT_VARIANT_NO_PIN
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
-#endif
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
     else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
 }
@@ -318,15 +316,14 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }
-#ifndef PT_STEPS
-#define PT_STEPS 1
-#endif
+        // kStepsPerCheck traversal steps between two looks at the refill condition (measured 1/2/3/4: 280.6/279.1/279.2/
+        // 280.1 ms per frame)
         if (canon) {
 #pragma unroll
-            for (int s = 0; s < PT_STEPS; s++) stream_step<COUNT, true>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, true>(sc, R, stk);
         } else {
 #pragma unroll
-            for (int s = 0; s < PT_STEPS; s++) stream_step<COUNT, false>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false>(sc, R, stk);
         }
     }
     flush_counts<COUNT>(R, a.cnt3);
