@@ -158,14 +158,10 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
         stk.put(R.sp, far_child);
         R.sp++;
     }
-#ifdef PT_VARIANT_POP_MERGE
-    R.pop = !(hl || hr);
-#else
     if (!(hl || hr)) {
         R.sp--;
         next = stk.get(R.sp);
     }
-#endif
     if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
     R.node = next;
 }
@@ -183,19 +179,6 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
     const float Dz = __fmaf_rn(d.z, v00.z, __fmaf_rn(d.y, v00.y, d.x * v00.x));
     const float invDz = 1.0f / Dz;
     const float t = Oz * invDz;
-#ifdef PT_VARIANT_TRI_FLAT
-    {
-        const float Ox = __fmaf_rn(o.z, v11.z, __fmaf_rn(o.y, v11.y, __fmaf_rn(o.x, v11.x, v11.w)));
-        const float Dx = __fmaf_rn(d.z, v11.z, __fmaf_rn(d.y, v11.y, d.x * v11.x));
-        const float u = __fmaf_rn(t, Dx, Ox);
-        const float Oy = __fmaf_rn(o.z, v22.z, __fmaf_rn(o.y, v22.y, __fmaf_rn(o.x, v22.x, v22.w)));
-        const float Dy = __fmaf_rn(d.z, v22.z, __fmaf_rn(d.y, v22.y, d.x * v22.x));
-        const float v = __fmaf_rn(t, Dy, Oy);
-        const bool hit = (t > kEps) & (t < R.t) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f);
-        R.t = hit ? t : R.t;
-        R.hid = hit ? (uint32_t)R.node : R.hid;
-    }
-#else
     if (t > kEps && t < R.t) {
         const float Ox = __fmaf_rn(o.z, v11.z, __fmaf_rn(o.y, v11.y, __fmaf_rn(o.x, v11.x, v11.w)));
         const float Dx = __fmaf_rn(d.z, v11.z, __fmaf_rn(d.y, v11.y, d.x * v11.x));
@@ -208,7 +191,6 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
             R.hid = (uint32_t)R.node;
         }
     }
-#endif
     int next = R.node + 1;
     if (flags & 1u) {
         R.sp--;
