@@ -18,6 +18,7 @@ OPT_POOL_SIZE, OPT_COUNT_TRAVERSAL, OPT_TIME_EXTEND, OPT_SLAB_BYTES, OPT_EXTEND_
 OPT_TUNE_REFILL_IDLE, OPT_TUNE_LDS_SLOTS = 6, 7
 OPT_ENV_PACK = 8
 OPT_STREAMS = 9
+OPT_TUNE_EXTEND_BLOCKS = 10
 
 
 class Plane(C.Structure):

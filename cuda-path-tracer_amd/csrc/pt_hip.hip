@@ -392,6 +392,7 @@ struct pt_ctx {
     int extend_mode = 2;       // 2: persistent single-step waves (default), 1: one 64-ray batch per wave step
     int refill_idle = kRefillIdle;
     int lds_slots = 26;
+    int extend_blocks = 8;     // cap on extend blocks per CU (the LDS stacks usually allow fewer)
     bool env_pack = true;      // use the packed environment texels when they are exact
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -529,7 +530,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
     const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
     const bool overflow = need > (uint32_t)lds_slots;
-    const int per_cu = std::max(1, std::min(8, 160 / lds_slots));
+    const int per_cu = std::max(1, std::min(ctx->extend_blocks, 160 / lds_slots));
     const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     const uint64_t want = ((uint64_t)n_upper + kBlock - 1) / kBlock;
     const int grid = (int)std::max<uint64_t>(1, std::min(cap, want));
@@ -681,6 +682,10 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value < 1 || value > (uint64_t)kMaxLanes) return fail(ctx, PT_ERR_ARG, "stream count %llu out of [1, %d]",
                                                                    (unsigned long long)value, kMaxLanes);
         ctx->nlanes = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_EXTEND_BLOCKS:
+        if (value < 1 || value > 8) return fail(ctx, PT_ERR_ARG, "extend blocks per CU %llu out of [1, 8]", (unsigned long long)value);
+        ctx->extend_blocks = (int)value;
         return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);

@@ -121,6 +121,7 @@ typedef struct pt_ctx pt_ctx;
                                        slots refilled; 1: one 64-ray batch per wave step, loop-per-phase traversal */
 #define PT_OPT_TUNE_REFILL_IDLE 6   /* extend tuning: refill a wave's ray slots once this many lanes are empty */
 #define PT_OPT_TUNE_LDS_SLOTS   7   /* extend tuning: traversal stack slots per lane kept in LDS (default 26) */
+#define PT_OPT_TUNE_EXTEND_BLOCKS 10 /* extend tuning: cap on resident extend blocks per CU (1..8, default 8) */
 #define PT_OPT_STREAMS          9   /* wavefront loops run side by side on streams of their own, each rendering a share of
                                        the samples (1..4, default 3); the film does not depend on it */
 #define PT_OPT_ENV_PACK         8   /* 1 (default): keep environment texels as shared-exponent word + pdf (8 B, tiled)
