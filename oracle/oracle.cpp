@@ -6,7 +6,7 @@
  * floating-point sequence is the same on x86 and on the GPU.  The BVH builder
  * uses NO fused operations (the reference's host builder is plain x86 code).
  *
- * "parity unpinned" for everything except the BVH buffers (see oracle.h).
+ * "parity unpinned" except for the pins listed in oracle.h.
  */
 #include "oracle.h"
 

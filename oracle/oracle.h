@@ -7,12 +7,17 @@
  * smoke check and the benchmark's cpu_baseline leg may load it; nothing that
  * ships may link, import or call it.
  *
- * Parity pin: the BVH builder/flattener is pinned by FNV-1a-64 known-answer
- * hashes of the buffers the reference's own builder hands to cudaMemcpy
- * (reference src/bvh.cu:298,302).  Everything on the device side (traversal,
- * shading, RNG, environment lookup) is "parity unpinned": the reference ships
- * no tests, fixtures or golden outputs for it and cannot be built here (CUDA
- * toolkit, cuRAND, inline PTX), so it is restated from the source text alone.
+ * Parity pins: (1) the random generator against the published Philox4x32-10
+ * known-answer vectors; (2) the BVH builder/flattener against the node,
+ * triangle-buffer and leaf counts recorded from the reference's own builder
+ * for its four shipped meshes (reference src/bvh.cu:298,302) -- the FNV-1a-64
+ * hashes recorded with those counts could NOT be reproduced, so the buffer
+ * contents themselves are unpinned; (3) traversal + triangle test against an
+ * independent float64 brute force.  Everything else on the device side
+ * (visit order details, shading, environment lookup) is "parity unpinned":
+ * the reference ships no tests, fixtures or golden outputs for it and cannot
+ * be built here (CUDA toolkit, cuRAND, inline PTX), so it is restated from
+ * the source text alone.
  *
  * Every struct here is laid out exactly like its pt_* twin in include/pt_api.h
  * so one ctypes definition can feed both libraries the same bytes.
