@@ -283,18 +283,12 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     bool degenerate = false;
     bool canon = false;          // wave-uniform: some ray in flight needs the NaN-rewriting slab test
     bool more_work = true;
-#ifdef PT_VARIANT_COUNT_TRIVIAL
-    uint32_t nodes_at_begin = 0, trivial = 0, trivial_sky = 0;
-#endif
 
     for (;;) {
         const int nidle = __popcll(__ballot(R.node == kSentinel));
         if (nidle == 64 || (more_work && nidle >= a.refill_idle)) {
             // retire finished rays, refill their slots
             if (ray != kNoRay && R.node == kSentinel) {
-#ifdef PT_VARIANT_COUNT_TRIVIAL
-                if (COUNT) { if (R.c_nodes - nodes_at_begin <= 1) { trivial++; if (R.hid == PT_PRIM_MISS) trivial_sky++; } }
-#endif
                 ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
@@ -315,9 +309,6 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             if (empty && rank < take) {
                 ray = next + rank;
                 ray_begin(sc, R, xyz(ld_stream(a.ro + ray)), xyz(ld_stream(a.rd + ray)), stk);
-#ifdef PT_VARIANT_COUNT_TRIVIAL
-                nodes_at_begin = R.c_nodes;
-#endif
                 degenerate = slab_degenerate(R.d);
             }
             next += take;
@@ -335,10 +326,6 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false>(sc, R, stk);
         }
     }
-#ifdef PT_VARIANT_COUNT_TRIVIAL
-    R.c_leaves = trivial;
-    R.c_tris = trivial_sky;
-#endif
     flush_counts<COUNT>(R, a.cnt3);
 }
 
