@@ -48,8 +48,11 @@ struct PathBuf {
 
 struct Counters {
     uint32_t n_in;                  // rays in the current buffer
-    uint32_t n_out;                 // rays the bounce kernel has appended to the other buffer so far
-    uint32_t pad[6];
+    uint32_t n_out;                 // rays appended to the other buffer so far (bounce, then generate)
+    uint32_t n_escaped;             // rays of this iteration that were created and found to leave the scene at once
+    uint32_t take;                  // camera paths the generate kernel starts in this iteration
+    unsigned long long gen_first;   // global index of the first of them
+    uint32_t pad[2];
     unsigned long long next_sample; // next global sample index to hand out
     unsigned long long total_samples;
     unsigned long long rays_total;
@@ -162,15 +165,42 @@ __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, ui
     return s;
 }
 
+// Appends the rays a block wants to keep to the other buffer: returns each keeper's slot.  One thread claims the
+// block's range with one atomic (every block adds to the same counter; one same-address atomic per 64-ray batch is
+// what these kernels would otherwise wait for) and adds the block's count of escaped rays to its counter.  Two
+// barriers; s_wave/s_base are double-buffered by `par` so that consecutive calls need no third one.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_append(bool keep, bool escaped, Counters *cnt, uint32_t (&s_wave)[2][BLOCK / 64],
+                                                 uint32_t (&s_base)[2], int par)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long kmask = __ballot(keep);
+    const uint32_t nesc = (uint32_t)__popcll(__ballot(escaped));
+    if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(kmask) | (nesc << 16);      // both counts are <= 64
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+        const uint32_t c = s_wave[par][w];
+        before += (uint32_t)w < wave ? c : 0u;
+        total += c;
+    }
+    if (threadIdx.x == 0) {
+        if (total >> 16) atomicAdd(&cnt->n_escaped, total >> 16);
+        s_base[par] = (total & 0xFFFFu) ? atomicAdd(&cnt->n_out, total & 0xFFFFu) : 0u;
+    }
+    __syncthreads();
+    return s_base[par] + (before & 0xFFFFu) +
+           __builtin_amdgcn_mbcnt_hi((uint32_t)(kmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kmask, 0));
+}
+
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          float4 *__restrict__ slab, uint32_t slab_first_sample,
                                                          uint32_t npix, uint32_t seed0, uint32_t seed1)
 {
-    constexpr int kBounceWaves = kBounceBlock / 64;
-    __shared__ uint32_t s_wave[2][kBounceWaves];
+    __shared__ uint32_t s_wave[2][kBounceBlock / 64];
     __shared__ uint32_t s_base[2];
     const uint32_t n = cnt->n_in;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * kBounceBlock;
     int par = 0;
     BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n);
@@ -204,21 +234,8 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
                 }
             }
         }
-        const unsigned long long mask = __ballot(alive);
-        if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < kBounceWaves; w++) {
-            const uint32_t c = s_wave[par][w];
-            woff += (uint32_t)w < wave ? c : 0u;
-            total += c;
-        }
-        // one thread claims the block's output range; the others shade meanwhile and meet it at the second barrier
-        uint32_t claimed = 0;
-        if (threadIdx.x == 0 && total) claimed = atomicAdd(&cnt->n_out, total);
-        const uint32_t r = woff + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
         f3 out = mk3(0, 0, 0), hitp = out;
+        bool escaped = false;
         if (alive) {
             const float4 mat = material_of(sc, hid);
             const int slot = mat_slot(material_type_of(sc, hid));
@@ -234,11 +251,13 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
             st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
             th.w = __uint_as_float(sample | ((k + 1) << 27));
+            // a new ray that leaves the scene at once ends its path here: its escape value is already in the slab, and
+            // the ray needs no slot, no traversal and no pass through the next bounce
+            escaped = ray_escapes_at_root(sc, hitp, out);
         }
-        if (threadIdx.x == 0) s_base[par] = claimed;
-        __syncthreads();
-        if (alive) {
-            const uint32_t dst = s_base[par] + r;
+        const bool keep = alive && !escaped;
+        const uint32_t dst = block_append<kBounceBlock>(keep, escaped, cnt, s_wave, s_base, par);
+        if (keep) {
             st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
             st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
             st_stream(B.thr + dst, th);
@@ -249,56 +268,74 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
 // --------------------------------------------------------------------------------------------------------------
 // generate: reference src/render.cu:93-127
 // --------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void new_take(const Counters *cnt, uint32_t P, uint32_t &n_out, uint32_t &take)
+// one thread, before generate: how many camera paths this iteration starts (as many as the buffer has room for)
+__global__ void k_take(Counters *cnt, uint32_t P)
 {
-    n_out = cnt->n_out;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const unsigned long long remaining = cnt->total_samples - cnt->next_sample;
-    const unsigned long long room = P - n_out;
-    take = (uint32_t)(remaining < room ? remaining : room);
+    const unsigned long long room = P - cnt->n_out;
+    const uint32_t take = (uint32_t)(remaining < room ? remaining : room);
+    cnt->take = take;
+    cnt->gen_first = cnt->next_sample;
+    cnt->next_sample += take;
+    cnt->paths_total += take;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, const Counters *cnt, uint32_t P, uint32_t W,
-                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
+__global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t W, uint32_t H,
+                                                     uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
                                                      float4 *__restrict__ slab)
 {
-    uint32_t n_out, take;
-    new_take(cnt, P, n_out, take);
-    const unsigned long long first = cnt->next_sample;
+    __shared__ uint32_t s_wave[2][kBlock / 64];
+    __shared__ uint32_t s_base[2];
+    const uint32_t take = cnt->take;
+    const unsigned long long first = cnt->gen_first;
     const uint32_t npix = W * H;
     const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < take; j += stride) {
-        const unsigned long long g = first + j;
-        const uint32_t s_local = (uint32_t)udiv_wide(g, npix);
-        const uint32_t r = (uint32_t)(g - (unsigned long long)s_local * npix);
-        const uint32_t sample = spp_begin + s_local;
-        uint32_t x, y;
-        pixel_of(r, W, H, x, y);
-        const uint32_t pixel = (H - y - 1) * W + x;
-        Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
-        f3 o, d;
-        camera_ray(sc.cam, W, H, x, y, rng, o, d);
-        const uint32_t dst = n_out + j;
-        const float4 th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-        st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
-        st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
-        st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
-        st_stream(B.thr + dst, th);
+    int par = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < take; base += stride, par ^= 1) {
+        const uint32_t j = base + threadIdx.x;
+        bool keep = false, escaped = false;
+        f3 o = mk3(0, 0, 0), d = o;
+        float4 th = make_float4(0, 0, 0, 0);
+        uint32_t pixel = 0;
+        if (j < take) {
+            const unsigned long long g = first + j;
+            const uint32_t s_local = (uint32_t)udiv_wide(g, npix);
+            const uint32_t r = (uint32_t)(g - (unsigned long long)s_local * npix);
+            const uint32_t sample = spp_begin + s_local;
+            uint32_t x, y;
+            pixel_of(r, W, H, x, y);
+            pixel = (H - y - 1) * W + x;
+            Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
+            camera_ray(sc.cam, W, H, x, y, rng, o, d);
+            th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+            st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
+            escaped = ray_escapes_at_root(sc, o, d);        // a camera ray into the sky: the path is complete
+            keep = !escaped;
+        }
+        const uint32_t dst = block_append<kBlock>(keep, escaped, cnt, s_wave, s_base, par);
+        if (keep) {
+            st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
+            st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
+            st_stream(B.thr + dst, th);
+        }
     }
 }
 
-__global__ void k_advance(Counters *cnt, uint32_t P)
+// one thread, after generate: the appended rays become the extend kernel's input.  A ray that escaped at creation
+// still is a closest-hit query that was answered (by the first step of the traversal, run where the ray was made), so
+// it counts as a ray, and as one node visit when the scene has a tree.
+__global__ void k_advance(Counters *cnt, uint32_t count_root_visits)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t n_out, take;
-    new_take(cnt, P, n_out, take);
-    const uint32_t n_in = n_out + take;
+    const uint32_t n_in = cnt->n_out;
     cnt->n_in = n_in;
-    cnt->next_sample += take;
-    cnt->paths_total += take;
-    cnt->rays_total += n_in;
+    cnt->rays_total += (unsigned long long)n_in + cnt->n_escaped;
+    if (count_root_visits) cnt->trav[0] += cnt->n_escaped;
     cnt->iter += 1;
     if (n_in) cnt->extend_nonempty += 1;
     cnt->n_out = 0;
+    cnt->n_escaped = 0;
 }
 
 // Divides a pixel's slab entries by the sample count, sums them in sample order and adds the sum to the film (float3
@@ -1107,9 +1144,11 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 if (ln.it > 0)
                     hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
                                        (uint32_t)ln.first, npix, s0, s1);
-                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
-                                   s0, s1, ln.slab);
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, P);
+                hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
+                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, W, H, (uint32_t)ln.first, s0,
+                                   s1, ln.slab);
+                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt,
+                                   (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u);
                 if (ctx->time_extend) {
                     while (ln.events.size() < ln.ev_used + 2) {
                         hipEvent_t ev;
