@@ -100,11 +100,12 @@ def main():
     ctx.film_bind(args.width, args.height, film.data_ptr())
     torch.cuda.synchronize()
 
-    acc = {"rays": 0, "ms_extend": 0.0, "ms_extend_busy": 0.0, "launches": 0, "ms_render": 0.0}
+    acc = {"rays": 0, "rays_escaped": 0, "ms_extend": 0.0, "ms_extend_busy": 0.0, "launches": 0, "ms_render": 0.0}
 
     def render_fn(begin, count, total, seed):
         st = ctx.render(begin, count, total, seed)
         acc["rays"] += st.rays
+        acc["rays_escaped"] += st.rays_escaped
         acc["ms_extend"] += st.ms_extend
         acc["ms_extend_busy"] += st.ms_extend_busy
         acc["launches"] += st.iterations
@@ -201,21 +202,28 @@ def main():
                 # --no-cpu-baseline) the committed figure of the same workload is used
                 b_ray = prof.get("algorithmic_bytes_per_ray")
         if b_ray is not None and acc["ms_extend"] > 0:
-            achieved = b_ray * acc["rays"] / (acc["ms_extend"] * 1e-3) / 1e9
+            # b_ray is the mean over ALL rays.  Rays that escaped where they were created (one root visit in the oracle's
+            # count) never reach an extend launch, so their bytes are taken out of what the extend launches are credited with.
+            has_tree = int(scene.desc.num_nodes) > 0
+            ext_bytes = b_ray * acc["rays"] - acc["rays_escaped"] * (B_STATE + (64.0 if has_tree else 0.0))
+            ext_rays = acc["rays"] - acc["rays_escaped"]
+            achieved = ext_bytes / (acc["ms_extend"] * 1e-3) / 1e9
+            out["config"]["rays_escaped_at_creation_per_frame"] = int(acc["rays_escaped"] / max(1, args.steps))
             out["roofline"] = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_extend",
                 "avg_launch_ms": round(acc["ms_extend"] / max(1, acc["launches"]), 4),
                 "launches": int(acc["launches"]),
-                "rays_per_launch": round(acc["rays"] / max(1, acc["launches"]), 1),
+                "rays_per_launch": round(ext_rays / max(1, acc["launches"]), 1),
+                "bytes_per_launch": round(ext_bytes / max(1, acc["launches"]), 0),
                 # The library runs several wavefront loops on streams of their own, so extend launches overlap each other
                 # (and the other kernels): a launch then has only part of the device and its own duration understates what
                 # the device does.  achieved_all_streams divides the same bytes by the time during which at least one
                 # extend launch was running.
                 "concurrent_streams": streams,
-                "achieved_all_streams": round(b_ray * acc["rays"] / (acc["ms_extend_busy"] * 1e-3) / 1e9, 1),
-                "frac_all_streams": round(b_ray * acc["rays"] / (acc["ms_extend_busy"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "achieved_all_streams": round(ext_bytes / (acc["ms_extend_busy"] * 1e-3) / 1e9, 1),
+                "frac_all_streams": round(ext_bytes / (acc["ms_extend_busy"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "extend_busy_share_of_frame": round(acc["ms_extend_busy"] / max(1e-9, acc["ms_render"]), 3),
             }
         else:

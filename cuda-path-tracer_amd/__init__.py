@@ -53,7 +53,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("iterations", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("ms_total", C.c_double), ("ms_extend", C.c_double),
                 ("nodes", C.c_uint64), ("tris", C.c_uint64), ("leaves", C.c_uint64),
-                ("ms_extend_busy", C.c_double)]
+                ("ms_extend_busy", C.c_double), ("rays_escaped", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

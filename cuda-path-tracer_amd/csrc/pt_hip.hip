@@ -59,6 +59,7 @@ struct Counters {
     unsigned long long paths_total;
     unsigned long long iter;
     unsigned long long extend_nonempty;
+    unsigned long long escaped_total; // rays ended where they were created (counted in rays_total too)
     unsigned long long trav[3];     // nodes, triangles, leaves (only with COUNT)
 };
 
@@ -331,6 +332,7 @@ __global__ void k_advance(Counters *cnt, uint32_t count_root_visits)
     const uint32_t n_in = cnt->n_out;
     cnt->n_in = n_in;
     cnt->rays_total += (unsigned long long)n_in + cnt->n_escaped;
+    cnt->escaped_total += cnt->n_escaped;
     if (count_root_visits) cnt->trav[0] += cnt->n_escaped;
     cnt->iter += 1;
     if (n_in) cnt->extend_nonempty += 1;
@@ -1201,6 +1203,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
             acc.paths += c.paths_total;
             acc.iterations += c.iter;
             acc.extend_launches += c.extend_nonempty;
+            acc.rays_escaped += c.escaped_total;
             acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
             for (size_t i = 0; i + 1 < ln.ev_used; i += 2) {
                 float b = 0, e = 0;

@@ -98,7 +98,7 @@ typedef struct {
 } pt_scene_desc;
 
 typedef struct {
-    uint64_t rays;              /* closest-hit queries = active slots summed over extend launches */
+    uint64_t rays;              /* closest-hit queries: active slots summed over extend launches + rays_escaped */
     uint64_t paths;             /* camera paths started */
     uint64_t iterations;        /* wavefront iterations (one extend launch each) */
     uint64_t extend_launches;   /* extend launches that had at least one ray */
@@ -109,6 +109,9 @@ typedef struct {
     uint64_t leaves;
     double ms_extend_busy;      /* time during which at least one extend launch was running (extend launches of
                                    different streams overlap, so this is below ms_extend when PT_OPT_STREAMS > 1) */
+    uint64_t rays_escaped;      /* queries answered where the ray was created: rays that hit no plane or sphere and miss
+                                   both child boxes of the BVH root (the traversal's own first step), so their paths end
+                                   without a slot in an extend launch */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
