@@ -117,17 +117,19 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f
     R.node = sc.has_bvh ? 0 : kSentinel;
 }
 
-// True when the ray leaves the scene without the tree having to be walked: it hits no plane and no sphere and misses
-// both child boxes of the root (or there is no mesh).  This is exactly what the traversal would find in its first
-// step -- same tests, same arithmetic, the NaN-rewriting slab test for every ray -- so a kernel that has just
-// created such a ray can end its path on the spot.  On the 868 k-triangle stand-in 37 % of all rays are of this kind.
-__device__ __forceinline__ bool ray_escapes_at_root(const DScene &sc, f3 o, f3 d)
+// Runs the traversal's own first step on a ray that has just been created: the plane and sphere tests, then the slab
+// test of the root's two child boxes against the hit found so far -- same tests, same arithmetic, the NaN-rewriting slab
+// test for every ray.  Returns true when nothing below the root can be hit (or there is no mesh): (t, hid) then IS the
+// ray's closest hit, exactly what the extend kernel would report.  hid == PT_PRIM_MISS in that case means the ray
+// leaves the scene.  On the 868 k-triangle stand-in 53 % of all rays are settled this way, 37 % of all rays escape.
+__device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d, float &t, uint32_t &hid)
 {
     Hit h;
     h.t = kFltMax; h.prim = PT_PRIM_MISS; h.n = mk3(0, 0, 0);
     for (uint32_t k = 0; k < sc.num_planes; k++) hit_plane(sc.planes[k], k, o, d, h);
     for (uint32_t k = 0; k < sc.num_spheres; k++) hit_sphere(sc.spheres[k], k, o, d, h);
-    if (h.prim != PT_PRIM_MISS) return false;
+    t = h.t;
+    hid = h.prim;
     if (!sc.has_bvh) return true;
     // the slab-test constants exactly as ray_setup forms them
     const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -136,8 +138,8 @@ __device__ __forceinline__ bool ray_escapes_at_root(const DScene &sc, f3 o, f3 d
                         ood.z != ood.z ? fl(0x7FC00000) : -ood.z);
     const float4 r0 = sc.recs[0], r1 = sc.recs[1], r2 = sc.recs[2];
     float t0;
-    const bool hl = hit_aabb<true>(inv, nood, r0.x, r0.y, r0.z, r0.w, r2.x, r2.y, kFltMax, t0);
-    const bool hr = hit_aabb<true>(inv, nood, r1.x, r1.y, r1.z, r1.w, r2.z, r2.w, kFltMax, t0);
+    const bool hl = hit_aabb<true>(inv, nood, r0.x, r0.y, r0.z, r0.w, r2.x, r2.y, t, t0);
+    const bool hr = hit_aabb<true>(inv, nood, r1.x, r1.y, r1.z, r1.w, r2.z, r2.w, t, t0);
     return !(hl || hr);
 }
 

@@ -47,12 +47,14 @@ struct PathBuf {
 };
 
 struct Counters {
-    uint32_t n_in;                  // rays in the current buffer
-    uint32_t n_out;                 // rays appended to the other buffer so far (bounce, then generate)
+    uint32_t n_in;                  // rays at the front of the current buffer: the ones extend has to trace
+    uint32_t n_out;                 // rays appended to the front of the other buffer so far (bounce, then generate)
     uint32_t n_escaped;             // rays of this iteration that were created and found to leave the scene at once
     uint32_t take;                  // camera paths the generate kernel starts in this iteration
     unsigned long long gen_first;   // global index of the first of them
-    uint32_t pad[2];
+    uint32_t n_back_in;             // rays at the back of the current buffer, slots [P - n_back_in, P): settled at creation,
+                                    // hit already stored, not for extend
+    uint32_t n_back_out;            // the same for the other buffer, being appended
     unsigned long long next_sample; // next global sample index to hand out
     unsigned long long total_samples;
     unsigned long long rays_total;
@@ -146,17 +148,24 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 ma
 // 342 / 335 / 341 and 124 / 117 / 121.
 constexpr int kBounceBlock = 512;
 
+// slot of the i-th ray of a buffer whose front holds n_front rays and whose back holds the rest
+__device__ __forceinline__ uint32_t buffer_slot(uint32_t i, uint32_t n_front, uint32_t n_total, uint32_t P)
+{
+    return i < n_front ? i : P - (n_total - n_front) + (i - n_front);
+}
+
 struct BounceIn { float4 th, d4, o4; float t; uint32_t hid; };
 
 // the whole state in one batch of loads: a path that ends here wastes 36 of the 56 bytes, but its neighbours in the
 // same cache lines need them anyway and nothing later waits for a second round trip
-__device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, uint32_t n)
+__device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, uint32_t n, uint32_t n_front, uint32_t P)
 {
     BounceIn s;
     s.th = make_float4(0, 0, 0, 0); s.d4 = s.th; s.o4 = s.th;
     s.t = kFltMax;
     s.hid = PT_PRIM_MISS;
     if (i < n) {
+        i = buffer_slot(i, n_front, n, P);
         s.t = ld_stream(A.t + i);
         s.th = ld_stream(A.thr + i);
         s.d4 = ld_stream(A.d + i);
@@ -166,18 +175,23 @@ __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, ui
     return s;
 }
 
-// Appends the rays a block wants to keep to the other buffer: returns each keeper's slot.  One thread claims the
-// block's range with one atomic (every block adds to the same counter; one same-address atomic per 64-ray batch is
-// what these kernels would otherwise wait for) and adds the block's count of escaped rays to its counter.  Two
-// barriers; s_wave/s_base are double-buffered by `par` so that consecutive calls need no third one.
+// Appends the rays a block wants to keep to the other buffer and returns each keeper's slot.  Rays that still need
+// the tree go to the front of the buffer (slots 0, 1, ...), rays whose hit was settled where they were made to its back
+// (slots P-1, P-2, ...), so that extend gets a dense range of exactly the rays it has work for.  One thread claims the
+// block's ranges with one atomic each (every block adds to the same counters; one same-address atomic per 64-ray
+// batch is what these kernels would otherwise wait for) and adds the block's count of escaped rays to its counter.
+// Two barriers; s_wave/s_base are double-buffered by `par` so that consecutive calls need no third one.
+enum { RAY_DROP = 0, RAY_FRONT = 1, RAY_BACK = 2, RAY_ESCAPED = 3 };
+
 template <int BLOCK>
-__device__ __forceinline__ uint32_t block_append(bool keep, bool escaped, Counters *cnt, uint32_t (&s_wave)[2][BLOCK / 64],
-                                                 uint32_t (&s_base)[2], int par)
+__device__ __forceinline__ uint32_t block_append(int cls, Counters *cnt, uint32_t P, uint32_t (&s_wave)[2][BLOCK / 64],
+                                                 uint32_t (&s_base)[2][2], int par)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const unsigned long long kmask = __ballot(keep);
-    const uint32_t nesc = (uint32_t)__popcll(__ballot(escaped));
-    if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(kmask) | (nesc << 16);      // both counts are <= 64
+    const unsigned long long fmask = __ballot(cls == RAY_FRONT), bmask = __ballot(cls == RAY_BACK);
+    const uint32_t nesc = (uint32_t)__popcll(__ballot(cls == RAY_ESCAPED));
+    // three counts of at most 64 each, 10 bits apiece (block sums stay below 1024)
+    if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(fmask) | ((uint32_t)__popcll(bmask) << 10) | (nesc << 20);
     __syncthreads();
     uint32_t before = 0, total = 0;
 #pragma unroll
@@ -187,31 +201,38 @@ __device__ __forceinline__ uint32_t block_append(bool keep, bool escaped, Counte
         total += c;
     }
     if (threadIdx.x == 0) {
-        if (total >> 16) atomicAdd(&cnt->n_escaped, total >> 16);
-        s_base[par] = (total & 0xFFFFu) ? atomicAdd(&cnt->n_out, total & 0xFFFFu) : 0u;
+        const uint32_t nf = total & 1023u, nb = (total >> 10) & 1023u, ne = total >> 20;
+        if (ne) atomicAdd(&cnt->n_escaped, ne);
+        s_base[par][0] = nf ? atomicAdd(&cnt->n_out, nf) : 0u;
+        s_base[par][1] = nb ? atomicAdd(&cnt->n_back_out, nb) : 0u;
     }
     __syncthreads();
-    return s_base[par] + (before & 0xFFFFu) +
-           __builtin_amdgcn_mbcnt_hi((uint32_t)(kmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kmask, 0));
+    if (cls == RAY_FRONT)
+        return s_base[par][0] + (before & 1023u) +
+               __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0));
+    return P - 1u - (s_base[par][1] + ((before >> 10) & 1023u) +
+                     __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask, 0)));
 }
 
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
-                                                         float4 *__restrict__ slab, uint32_t slab_first_sample,
-                                                         uint32_t npix, uint32_t seed0, uint32_t seed1)
+                                                         uint32_t P, float4 *__restrict__ slab,
+                                                         uint32_t slab_first_sample, uint32_t npix, uint32_t seed0,
+                                                         uint32_t seed1)
 {
     __shared__ uint32_t s_wave[2][kBounceBlock / 64];
-    __shared__ uint32_t s_base[2];
-    const uint32_t n = cnt->n_in;
+    __shared__ uint32_t s_base[2][2];
+    const uint32_t n_front = cnt->n_in;
+    const uint32_t n = n_front + cnt->n_back_in;
     const uint32_t stride = gridDim.x * kBounceBlock;
     int par = 0;
-    BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n);
+    BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n, n_front, P);
     // the trip count is the same for every thread of a block (barriers inside)
     for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
         // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming loads
         // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
         const BounceIn in = nxt;
-        nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u);
+        nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u, n_front, P);
         bool alive = false;
         float4 th = in.th;
         const float4 d4 = in.d4, o4 = in.o4;
@@ -236,7 +257,9 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             }
         }
         f3 out = mk3(0, 0, 0), hitp = out;
-        bool escaped = false;
+        int cls = RAY_DROP;
+        float nt = kFltMax;
+        uint32_t nhid = PT_PRIM_MISS;
         if (alive) {
             const float4 mat = material_of(sc, hid);
             const int slot = mat_slot(material_type_of(sc, hid));
@@ -252,16 +275,21 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
             st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
             th.w = __uint_as_float(sample | ((k + 1) << 27));
-            // a new ray that leaves the scene at once ends its path here: its escape value is already in the slab, and
-            // the ray needs no slot, no traversal and no pass through the next bounce
-            escaped = ray_escapes_at_root(sc, hitp, out);
+            // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
+            // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
+            // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
+            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
+            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
-        const bool keep = alive && !escaped;
-        const uint32_t dst = block_append<kBounceBlock>(keep, escaped, cnt, s_wave, s_base, par);
-        if (keep) {
+        const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par);
+        if (cls == RAY_FRONT || cls == RAY_BACK) {
             st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
             st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
             st_stream(B.thr + dst, th);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
         }
     }
 }
@@ -274,7 +302,7 @@ __global__ void k_take(Counters *cnt, uint32_t P)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const unsigned long long remaining = cnt->total_samples - cnt->next_sample;
-    const unsigned long long room = P - cnt->n_out;
+    const unsigned long long room = P - cnt->n_out - cnt->n_back_out;
     const uint32_t take = (uint32_t)(remaining < room ? remaining : room);
     cnt->take = take;
     cnt->gen_first = cnt->next_sample;
@@ -282,12 +310,12 @@ __global__ void k_take(Counters *cnt, uint32_t P)
     cnt->paths_total += take;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t W, uint32_t H,
-                                                     uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
+__global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t P, uint32_t W,
+                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
                                                      float4 *__restrict__ slab)
 {
     __shared__ uint32_t s_wave[2][kBlock / 64];
-    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_base[2][2];
     const uint32_t take = cnt->take;
     const unsigned long long first = cnt->gen_first;
     const uint32_t npix = W * H;
@@ -295,7 +323,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
     int par = 0;
     for (uint32_t base = blockIdx.x * kBlock; base < take; base += stride, par ^= 1) {
         const uint32_t j = base + threadIdx.x;
-        bool keep = false, escaped = false;
+        int cls = RAY_DROP;
+        float nt = kFltMax;
+        uint32_t nhid = PT_PRIM_MISS;
         f3 o = mk3(0, 0, 0), d = o;
         float4 th = make_float4(0, 0, 0, 0);
         uint32_t pixel = 0;
@@ -311,32 +341,42 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
             camera_ray(sc.cam, W, H, x, y, rng, o, d);
             th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
             st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
-            escaped = ray_escapes_at_root(sc, o, d);        // a camera ray into the sky: the path is complete
-            keep = !escaped;
+            // a camera ray into the sky completes its path here; one that hits a plane or sphere in front of the mesh
+            // gets its hit stored now
+            const bool settled = ray_settled_at_root(sc, o, d, nt, nhid);
+            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
-        const uint32_t dst = block_append<kBlock>(keep, escaped, cnt, s_wave, s_base, par);
-        if (keep) {
+        const uint32_t dst = block_append<kBlock>(cls, cnt, P, s_wave, s_base, par);
+        if (cls == RAY_FRONT || cls == RAY_BACK) {
             st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
             st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
             st_stream(B.thr + dst, th);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
         }
     }
 }
 
-// one thread, after generate: the appended rays become the extend kernel's input.  A ray that escaped at creation
-// still is a closest-hit query that was answered (by the first step of the traversal, run where the ray was made), so
-// it counts as a ray, and as one node visit when the scene has a tree.
+// one thread, after generate: the rays appended at the front become the extend kernel's input.  A ray that was settled
+// where it was made (it escaped, or it hit a plane or sphere in front of the mesh) still is a closest-hit query that
+// was answered -- by the first step of the traversal -- so it counts as a ray, and as one node visit when the scene has
+// a tree.
 __global__ void k_advance(Counters *cnt, uint32_t count_root_visits)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const uint32_t n_in = cnt->n_out;
-    cnt->n_in = n_in;
-    cnt->rays_total += (unsigned long long)n_in + cnt->n_escaped;
-    cnt->escaped_total += cnt->n_escaped;
-    if (count_root_visits) cnt->trav[0] += cnt->n_escaped;
+    const uint32_t n_front = cnt->n_out, n_back = cnt->n_back_out;
+    const uint32_t settled = n_back + cnt->n_escaped;
+    cnt->n_in = n_front;
+    cnt->n_back_in = n_back;
+    cnt->rays_total += (unsigned long long)n_front + settled;
+    cnt->escaped_total += settled;
+    if (count_root_visits) cnt->trav[0] += settled;
     cnt->iter += 1;
-    if (n_in) cnt->extend_nonempty += 1;
+    if (n_front) cnt->extend_nonempty += 1;
     cnt->n_out = 0;
+    cnt->n_back_out = 0;
     cnt->n_escaped = 0;
 }
 
@@ -1144,11 +1184,11 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
                                                                              ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
                 if (ln.it > 0)
-                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, ln.slab,
+                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
                                        (uint32_t)ln.first, npix, s0, s1);
                 hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
-                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, W, H, (uint32_t)ln.first, s0,
-                                   s1, ln.slab);
+                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
+                                   s0, s1, ln.slab);
                 hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt,
                                    (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u);
                 if (ctx->time_extend) {
@@ -1176,7 +1216,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                         const int old = (int)((ln.it - 2) & 3);
                         HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
                         const Counters &c = ln.h_cnt[old];
-                        if (c.n_in == 0 && c.next_sample >= c.total_samples) {
+                        if (c.n_in == 0 && c.n_back_in == 0 && c.next_sample >= c.total_samples) {
                             ln.done = true;
                             live--;
                         }
