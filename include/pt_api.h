@@ -109,9 +109,10 @@ typedef struct {
     uint64_t leaves;
     double ms_extend_busy;      /* time during which at least one extend launch was running (extend launches of
                                    different streams overlap, so this is below ms_extend when PT_OPT_STREAMS > 1) */
-    uint64_t rays_escaped;      /* queries answered where the ray was created: rays that hit no plane or sphere and miss
-                                   both child boxes of the BVH root (the traversal's own first step), so their paths end
-                                   without a slot in an extend launch */
+    uint64_t rays_escaped;      /* queries answered where the ray was created, by the traversal's own first step: rays that
+                                   miss both child boxes of the BVH root (given their plane/sphere hit, if any).  Those
+                                   that hit nothing end their path at once; the others carry their hit and skip extend.
+                                   Neither takes a slot in an extend launch. */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
