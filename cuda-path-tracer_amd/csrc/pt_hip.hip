@@ -175,95 +175,43 @@ __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, ui
     return s;
 }
 
-// Appends the rays a block wants to keep to the other buffer.  Rays that still need the tree go to the front of the
-// buffer (slots 0, 1, ...), rays whose hit was settled where they were made to its back (slots P-1, P-2, ...), so that
-// extend gets a dense range of exactly the rays it has work for.  One thread claims the block's ranges with one atomic
-// each (every block adds to the same counters; one same-address atomic per 64-ray batch is what these kernels would
-// otherwise wait for) and adds the block's count of escaped rays to its counter.
-//
-// The claim is pipelined: step() publishes the counts of the CURRENT batch and hands back the slots of the PREVIOUS one,
-// whose claim was issued a whole batch of work ago, so nobody waits for an atomic's round trip and one barrier per batch
-// is enough.  The caller keeps the previous batch's rays in registers until then and calls flush() after its last batch.
+// Appends the rays a block wants to keep to the other buffer and returns each keeper's slot.  Rays that still need
+// the tree go to the front of the buffer (slots 0, 1, ...), rays whose hit was settled where they were made to its back
+// (slots P-1, P-2, ...), so that extend gets a dense range of exactly the rays it has work for.  One thread claims the
+// block's ranges with one atomic each (every block adds to the same counters; one same-address atomic per 64-ray
+// batch is what these kernels would otherwise wait for) and adds the block's count of escaped rays to its counter.
+// Two barriers; s_wave/s_base are double-buffered by `par` so that consecutive calls need no third one.
 enum { RAY_DROP = 0, RAY_FRONT = 1, RAY_BACK = 2, RAY_ESCAPED = 3 };
 
 template <int BLOCK>
-struct BlockAppender {
-    uint32_t (&s_wave)[2][BLOCK / 64];     // per-wave counts of the current batch, double-buffered
-    uint32_t (&s_base)[2][2];              // claimed front / back range of the previous batch, double-buffered
-    Counters *cnt;
-    uint32_t P;
-    int par;
-    uint32_t claim_f, claim_b;             // thread 0: the pending batch's claims (results of atomics in flight)
-    int p_cls;                             // this thread's ray of the pending batch: class and rank within the block
-    uint32_t p_rank;
-
-    __device__ __forceinline__ BlockAppender(uint32_t (&w)[2][BLOCK / 64], uint32_t (&b)[2][2], Counters *c, uint32_t pool)
-        : s_wave(w), s_base(b), cnt(c), P(pool), par(0), claim_f(0), claim_b(0), p_cls(RAY_DROP), p_rank(0)
-    {
-    }
-
-    __device__ __forceinline__ uint32_t pending_slot(int &prev_cls)
-    {
-        prev_cls = p_cls;
-        p_cls = RAY_DROP;
-        return prev_cls == RAY_FRONT ? s_base[par ^ 1][0] + p_rank : P - 1u - (s_base[par ^ 1][1] + p_rank);
-    }
-
-    // cls: what this thread's new ray is.  Returns the slot of this thread's ray of the previous batch; prev_cls tells
-    // whether it has one (RAY_FRONT / RAY_BACK).
-    __device__ __forceinline__ uint32_t step(int cls, int &prev_cls)
-    {
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const unsigned long long fmask = __ballot(cls == RAY_FRONT), bmask = __ballot(cls == RAY_BACK);
-        const uint32_t nesc = (uint32_t)__popcll(__ballot(cls == RAY_ESCAPED));
-        // three counts of at most 64 each, 10 bits apiece (block sums stay below 1024)
-        if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(fmask) | ((uint32_t)__popcll(bmask) << 10) | (nesc << 20);
-        if (threadIdx.x == 0) { s_base[par ^ 1][0] = claim_f; s_base[par ^ 1][1] = claim_b; }
-        __syncthreads();
-        const uint32_t prev_dst = pending_slot(prev_cls);
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) {
-            const uint32_t c = s_wave[par][w];
-            before += (uint32_t)w < wave ? c : 0u;
-            total += c;
-        }
-        if (threadIdx.x == 0) {
-            const uint32_t nf = total & 1023u, nb = (total >> 10) & 1023u, ne = total >> 20;
-            if (ne) atomicAdd(&cnt->n_escaped, ne);
-            claim_f = nf ? atomicAdd(&cnt->n_out, nf) : 0u;
-            claim_b = nb ? atomicAdd(&cnt->n_back_out, nb) : 0u;
-        }
-        p_cls = cls;
-        p_rank = cls == RAY_FRONT
-                     ? (before & 1023u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0))
-                     : ((before >> 10) & 1023u) + __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask, 0));
-        par ^= 1;
-        return prev_dst;
-    }
-
-    // after the last batch: the slot of its ray
-    __device__ __forceinline__ uint32_t flush(int &prev_cls)
-    {
-        if (threadIdx.x == 0) { s_base[par ^ 1][0] = claim_f; s_base[par ^ 1][1] = claim_b; }
-        __syncthreads();
-        return pending_slot(prev_cls);
-    }
-};
-
-// a new ray on its way into the other buffer
-struct NewRay { f3 o, d; float4 th; uint32_t pixel_bits; float t; uint32_t hid; };
-
-__device__ __forceinline__ void store_new_ray(const PathBuf &B, uint32_t dst, int cls, const NewRay &r)
+__device__ __forceinline__ uint32_t block_append(int cls, Counters *cnt, uint32_t P, uint32_t (&s_wave)[2][BLOCK / 64],
+                                                 uint32_t (&s_base)[2][2], int par)
 {
-    if (cls != RAY_FRONT && cls != RAY_BACK) return;
-    st_stream(B.o + dst, make_float4(r.o.x, r.o.y, r.o.z, 0.0f));
-    st_stream(B.d + dst, make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(r.pixel_bits)));
-    st_stream(B.thr + dst, r.th);
-    if (cls == RAY_BACK) {            // settled where it was made: the hit goes with it, extend never sees it
-        st_stream(B.hid + dst, r.hid);
-        st_stream(B.t + dst, r.t);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long fmask = __ballot(cls == RAY_FRONT), bmask = __ballot(cls == RAY_BACK);
+    const uint32_t nesc = (uint32_t)__popcll(__ballot(cls == RAY_ESCAPED));
+    // three counts of at most 64 each, 10 bits apiece (block sums stay below 1024)
+    if (lane == 0) s_wave[par][wave] = (uint32_t)__popcll(fmask) | ((uint32_t)__popcll(bmask) << 10) | (nesc << 20);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+        const uint32_t c = s_wave[par][w];
+        before += (uint32_t)w < wave ? c : 0u;
+        total += c;
     }
+    if (threadIdx.x == 0) {
+        const uint32_t nf = total & 1023u, nb = (total >> 10) & 1023u, ne = total >> 20;
+        if (ne) atomicAdd(&cnt->n_escaped, ne);
+        s_base[par][0] = nf ? atomicAdd(&cnt->n_out, nf) : 0u;
+        s_base[par][1] = nb ? atomicAdd(&cnt->n_back_out, nb) : 0u;
+    }
+    __syncthreads();
+    if (cls == RAY_FRONT)
+        return s_base[par][0] + (before & 1023u) +
+               __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask, 0));
+    return P - 1u - (s_base[par][1] + ((before >> 10) & 1023u) +
+                     __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask, 0)));
 }
 
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
@@ -273,14 +221,13 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
 {
     __shared__ uint32_t s_wave[2][kBounceBlock / 64];
     __shared__ uint32_t s_base[2][2];
-    BlockAppender<kBounceBlock> app(s_wave, s_base, cnt, P);
     const uint32_t n_front = cnt->n_in;
     const uint32_t n = n_front + cnt->n_back_in;
     const uint32_t stride = gridDim.x * kBounceBlock;
+    int par = 0;
     BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n, n_front, P);
-    NewRay prev{};
-    // the trip count is the same for every thread of a block (a barrier inside)
-    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride) {
+    // the trip count is the same for every thread of a block (barriers inside)
+    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
         // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming loads
         // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
@@ -309,39 +256,42 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
                 }
             }
         }
-        NewRay cur{};
+        f3 out = mk3(0, 0, 0), hitp = out;
         int cls = RAY_DROP;
+        float nt = kFltMax;
+        uint32_t nhid = PT_PRIM_MISS;
         if (alive) {
             const float4 mat = material_of(sc, hid);
             const int slot = mat_slot(material_type_of(sc, hid));
             const f3 o = xyz(o4), d = xyz(d4);
             uint32_t prim;
             const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
-            cur.o = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
+            hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
             float4 e;
-            if (slot == 0) cur.d = shade_dir<0>(sc, d, n3, mat, rng, th, e);
-            else if (slot == 1) cur.d = shade_dir<1>(sc, d, n3, mat, rng, th, e);
-            else if (slot == 2) cur.d = shade_dir<2>(sc, d, n3, mat, rng, th, e);
-            else cur.d = shade_dir<3>(sc, d, n3, mat, rng, th, e);
+            if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
+            else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
+            else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
+            else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
             st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
             th.w = __uint_as_float(sample | ((k + 1) << 27));
-            cur.th = th;
-            cur.pixel_bits = pixel;
             // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
             // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
             // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
-            const bool settled = ray_settled_at_root(sc, cur.o, cur.d, cur.t, cur.hid);
-            cls = !settled ? RAY_FRONT : (cur.hid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
+            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
-        int prev_cls;
-        const uint32_t dst = app.step(cls, prev_cls);
-        store_new_ray(B, dst, prev_cls, prev);
-        prev = cur;
+        const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par);
+        if (cls == RAY_FRONT || cls == RAY_BACK) {
+            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
+            st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
+            st_stream(B.thr + dst, th);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
+        }
     }
-    int prev_cls;
-    const uint32_t dst = app.flush(prev_cls);
-    store_new_ray(B, dst, prev_cls, prev);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -366,16 +316,19 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
 {
     __shared__ uint32_t s_wave[2][kBlock / 64];
     __shared__ uint32_t s_base[2][2];
-    BlockAppender<kBlock> app(s_wave, s_base, cnt, P);
     const uint32_t take = cnt->take;
     const unsigned long long first = cnt->gen_first;
     const uint32_t npix = W * H;
     const uint32_t stride = gridDim.x * kBlock;
-    NewRay prev{};
-    for (uint32_t base = blockIdx.x * kBlock; base < take; base += stride) {
+    int par = 0;
+    for (uint32_t base = blockIdx.x * kBlock; base < take; base += stride, par ^= 1) {
         const uint32_t j = base + threadIdx.x;
-        NewRay cur{};
         int cls = RAY_DROP;
+        float nt = kFltMax;
+        uint32_t nhid = PT_PRIM_MISS;
+        f3 o = mk3(0, 0, 0), d = o;
+        float4 th = make_float4(0, 0, 0, 0);
+        uint32_t pixel = 0;
         if (j < take) {
             const unsigned long long g = first + j;
             const uint32_t s_local = (uint32_t)udiv_wide(g, npix);
@@ -383,25 +336,27 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
             const uint32_t sample = spp_begin + s_local;
             uint32_t x, y;
             pixel_of(r, W, H, x, y);
-            const uint32_t pixel = (H - y - 1) * W + x;
+            pixel = (H - y - 1) * W + x;
             Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
-            camera_ray(sc.cam, W, H, x, y, rng, cur.o, cur.d);
-            cur.th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-            cur.pixel_bits = pixel;
-            st_stream(slab + (size_t)s_local * npix + pixel, escape_value(cur.th, env_lookup(sc, cur.d)));
+            camera_ray(sc.cam, W, H, x, y, rng, o, d);
+            th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
+            st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
             // a camera ray into the sky completes its path here; one that hits a plane or sphere in front of the mesh
             // gets its hit stored now
-            const bool settled = ray_settled_at_root(sc, cur.o, cur.d, cur.t, cur.hid);
-            cls = !settled ? RAY_FRONT : (cur.hid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+            const bool settled = ray_settled_at_root(sc, o, d, nt, nhid);
+            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
-        int prev_cls;
-        const uint32_t dst = app.step(cls, prev_cls);
-        store_new_ray(B, dst, prev_cls, prev);
-        prev = cur;
+        const uint32_t dst = block_append<kBlock>(cls, cnt, P, s_wave, s_base, par);
+        if (cls == RAY_FRONT || cls == RAY_BACK) {
+            st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
+            st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
+            st_stream(B.thr + dst, th);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
+        }
     }
-    int prev_cls;
-    const uint32_t dst = app.flush(prev_cls);
-    store_new_ray(B, dst, prev_cls, prev);
 }
 
 // one thread, after generate: the rays appended at the front become the extend kernel's input.  A ray that was settled
