@@ -254,6 +254,27 @@ def test_packed_environment_texels_change_nothing(pkg):
     c.close()
 
 
+def test_rays_settled_where_they_are_made_are_counted(pkg, ctx):
+    """Rays whose closest hit follows from the plane/sphere tests and the BVH root's child boxes never reach an extend
+    launch but still count as rays: with no mesh that is every ray, with one it is a part, and the totals stay the
+    oracle's (ray counts within the flipped-path rate, node visits equal on hit-for-hit identical batches)."""
+    W, H, spp = 96, 64, 4
+    scene = S.spheres_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=3)
+    _, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=3)
+    assert st.rays_escaped == st.rays and st.extend_launches == 0
+    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=3)
+    _, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=3)
+    assert 0 < st.rays_escaped < st.rays
+    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
+
+
 def test_film_does_not_depend_on_the_stream_count(pkg, ctx):
     """pt_render runs up to four wavefront loops side by side, each on a share of the samples; which loop renders a
     sample must not show in the film."""
