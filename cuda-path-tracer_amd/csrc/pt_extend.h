@@ -140,34 +140,7 @@ __device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d
     float t0;
     const bool hl = hit_aabb<true>(inv, nood, r0.x, r0.y, r0.z, r0.w, r2.x, r2.y, t, t0);
     const bool hr = hit_aabb<true>(inv, nood, r1.x, r1.y, r1.z, r1.w, r2.z, r2.w, t, t0);
-#ifdef PT_VARIANT_SETTLE2
-    // second level: a root child whose box is hit but whose own two child boxes are both missed ends there as well
-    // (no triangle is tested on the way, so the visit order does not matter)
-    const float4 r3 = sc.recs[3];
-    const uint32_t cl = (uint32_t)fi(r3.x), cr = (uint32_t)fi(r3.y);
-    bool open = false;
-    if (hl) {
-        if (cl >= sc.first_tri) open = true;
-        else {
-            const float4 *q = sc.recs + (size_t)cl * 4;
-            const float4 a0 = q[0], a1 = q[1], a2 = q[2];
-            open = hit_aabb<true>(inv, nood, a0.x, a0.y, a0.z, a0.w, a2.x, a2.y, t, t0) |
-                   hit_aabb<true>(inv, nood, a1.x, a1.y, a1.z, a1.w, a2.z, a2.w, t, t0);
-        }
-    }
-    if (hr && !open) {
-        if (cr >= sc.first_tri) open = true;
-        else {
-            const float4 *q = sc.recs + (size_t)cr * 4;
-            const float4 a0 = q[0], a1 = q[1], a2 = q[2];
-            open = hit_aabb<true>(inv, nood, a0.x, a0.y, a0.z, a0.w, a2.x, a2.y, t, t0) |
-                   hit_aabb<true>(inv, nood, a1.x, a1.y, a1.z, a1.w, a2.z, a2.w, t, t0);
-        }
-    }
-    return !open;
-#else
     return !(hl || hr);
-#endif
 }
 
 // Unit normal (reference src/render.cu:41) and reported primitive id of a hit, from the hit id extend stores.  The
