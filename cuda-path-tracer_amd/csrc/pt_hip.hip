@@ -431,7 +431,10 @@ __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint3
 // ================================================================================================================
 // host side
 // ================================================================================================================
-// One independent wavefront (own stream, path buffers and counters) rendering a share of the samples.
+// One independent wavefront loop (own stream, path buffers and counters) rendering a share of a slab's samples.  The
+// lanes of a context run side by side: the traversal kernel is bound by record fetches through the caches, bounce and
+// generate by streaming state through HBM, so one lane's extend runs beside another lane's bounce.  Measured on the
+// headline frame, 1 / 2 / 3 / 4 lanes: 324 / 280 / 269 / 288 ms.
 constexpr int kMaxLanes = 4;
 struct Lane {
     hipStream_t stream = nullptr;
@@ -643,6 +646,79 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     }
 #undef PT_LAUNCH
     HIPCHK(ctx, hipGetLastError());
+    return PT_OK;
+}
+
+// Points a lane at its share of a slab: `count` samples from `first`, slab entries at `slab`.
+static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, float4 *slab, int nlanes)
+{
+    const uint64_t npix = (uint64_t)ctx->W * ctx->H;
+    ln.first = first;
+    ln.count = count;
+    ln.total = npix * count;
+    ln.slab = slab;
+    // path pool: the lane's share of the configured size, but no more slots than it has paths
+    const uint64_t want = (ln.total + 65535) & ~65535ull;
+    ln.P = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1024u, ctx->pool / (uint32_t)nlanes), want);
+    int rc = ensure_pool(ctx, ln, ln.P);
+    if (rc != PT_OK) return rc;
+    ln.min_iters = (ln.total + ln.P - 1) / ln.P;
+    ln.it = 0;
+    ln.cur = 0;
+    ln.ev_used = 0;
+    ln.done = false;
+    Counters &init = ln.h_cnt[4];
+    init = Counters{};
+    init.total_samples = ln.total;
+    HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_slab_free, 0));     // the previous slab has been reduced
+    HIPCHK(ctx, hipMemcpyAsync(ln.cnt, &init, sizeof init, hipMemcpyHostToDevice, ln.stream));
+    return PT_OK;
+}
+
+// Queues one wavefront iteration of a lane (bounce, take, generate, advance, extend) and, once the lane can have run
+// out of work, polls its device counters two iterations behind the launch front; sets ln.done when they say so.
+static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
+{
+    const uint32_t W = ctx->W, H = ctx->H, npix = W * H, P = ln.P;
+    hipStream_t ls = ln.stream;
+    PathBuf A = ln.buf[ln.cur], B = ln.buf[ln.cur ^ 1];
+    const int gs = stream_grid(ctx, P);
+    const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
+                                                                 ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
+    if (ln.it > 0)
+        hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
+                           (uint32_t)ln.first, npix, s0, s1);
+    hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
+    hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first, s0, s1,
+                       ln.slab);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u);
+    if (ctx->time_extend) {
+        while (ln.events.size() < ln.ev_used + 2) {
+            hipEvent_t ev;
+            HIPCHK(ctx, hipEventCreate(&ev));
+            ln.events.push_back(ev);
+        }
+        HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used], ls));
+    }
+    int rc = launch_extend(ctx, ls, ln.cnt, true, &ln.gstk, &ln.gstk_threads, B.o, B.d, 0, P, B.hid, B.t);
+    if (rc != PT_OK) return rc;
+    if (ctx->time_extend) {
+        HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used + 1], ls));
+        ln.ev_used += 2;
+    }
+    ln.cur ^= 1;
+    ln.it++;
+    if (ln.it >= ln.min_iters) {
+        const int slot = (int)(ln.it & 3);
+        HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[slot], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ls));
+        HIPCHK(ctx, hipEventRecord(ln.poll_ev[slot], ls));
+        if (ln.it >= ln.min_iters + 2) {
+            const int old = (int)((ln.it - 2) & 3);
+            HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
+            const Counters &c = ln.h_cnt[old];
+            if (c.n_in == 0 && c.n_back_in == 0 && c.next_sample >= c.total_samples) ln.done = true;
+        }
+    }
     return PT_OK;
 }
 
@@ -1143,85 +1219,22 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         const uint64_t first = spp_begin + done_samples;
         const uint64_t count = std::min<uint64_t>(slab_samples, spp_count - done_samples);
 
-        // The slab's samples are split over the lanes.  Each lane is a complete wavefront loop on its own stream, so
-        // one lane's traversal kernel (bound by record fetches through the caches) runs beside another lane's bounce
-        // and generate kernels (bound by streaming state through HBM).  Measured on the headline frame, 1 / 2 / 3 / 4
-        // lanes: 334 / 309 / 305 / 324 ms; on an eighth of its samples (one rank of eight): 43.6 / 41.2 / 39.7 ms.  Which lane renders a sample does not change its slab entry, so the film does not depend on
-        // the lane count.
+        // The slab's samples are split over the lanes (see Lane).  Which lane renders a sample does not change its slab
+        // entry, so the film does not depend on the lane count.
         const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
         for (int k = 0; k < nl; k++) {
-            Lane &ln = ctx->lanes[k];
             const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
-            ln.first = first + b;
-            ln.count = e - b;
-            ln.total = (uint64_t)npix * ln.count;
-            ln.slab = ctx->slab + (size_t)b * npix;
-            // path pool: the lane's share of the configured size, but no more slots than it has paths
-            const uint64_t want = (ln.total + 65535) & ~65535ull;
-            ln.P = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1024u, ctx->pool / (uint32_t)nl), want);
-            int rc = ensure_pool(ctx, ln, ln.P);
+            int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
             if (rc != PT_OK) return rc;
-            ln.min_iters = (ln.total + ln.P - 1) / ln.P;
-            ln.it = 0;
-            ln.cur = 0;
-            ln.ev_used = 0;
-            ln.done = false;
-            Counters &init = ln.h_cnt[4];
-            init = Counters{};
-            init.total_samples = ln.total;
-            HIPCHK(ctx, hipStreamWaitEvent(ln.stream, ctx->ev_slab_free, 0));     // the previous slab has been reduced
-            HIPCHK(ctx, hipMemcpyAsync(ln.cnt, &init, sizeof init, hipMemcpyHostToDevice, ln.stream));
         }
-
+        // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
         for (int live = nl; live > 0;) {
             for (int k = 0; k < nl; k++) {
                 Lane &ln = ctx->lanes[k];
                 if (ln.done) continue;
-                hipStream_t ls = ln.stream;
-                const uint32_t P = ln.P;
-                PathBuf A = ln.buf[ln.cur], B = ln.buf[ln.cur ^ 1];
-                const int gs = stream_grid(ctx, P);
-                const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
-                                                                             ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
-                if (ln.it > 0)
-                    hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
-                                       (uint32_t)ln.first, npix, s0, s1);
-                hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
-                hipLaunchKernelGGL(k_generate, dim3(gs), dim3(kBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first,
-                                   s0, s1, ln.slab);
-                hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt,
-                                   (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u);
-                if (ctx->time_extend) {
-                    while (ln.events.size() < ln.ev_used + 2) {
-                        hipEvent_t ev;
-                        HIPCHK(ctx, hipEventCreate(&ev));
-                        ln.events.push_back(ev);
-                    }
-                    HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used], ls));
-                }
-                int rc = launch_extend(ctx, ls, ln.cnt, true, &ln.gstk, &ln.gstk_threads, B.o, B.d, 0, P, B.hid, B.t);
+                int rc = lane_iterate(ctx, ln, s0, s1);
                 if (rc != PT_OK) return rc;
-                if (ctx->time_extend) {
-                    HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used + 1], ls));
-                    ln.ev_used += 2;
-                }
-                ln.cur ^= 1;
-                ln.it++;
-                if (ln.it >= ln.min_iters) {
-                    // poll the device counters two iterations behind the launch front
-                    const int slot = (int)(ln.it & 3);
-                    HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[slot], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ls));
-                    HIPCHK(ctx, hipEventRecord(ln.poll_ev[slot], ls));
-                    if (ln.it >= ln.min_iters + 2) {
-                        const int old = (int)((ln.it - 2) & 3);
-                        HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
-                        const Counters &c = ln.h_cnt[old];
-                        if (c.n_in == 0 && c.n_back_in == 0 && c.next_sample >= c.total_samples) {
-                            ln.done = true;
-                            live--;
-                        }
-                    }
-                }
+                if (ln.done) live--;
             }
         }
         // every path of this slab has ended and its entry holds what it contributes: fold the slab into the film
