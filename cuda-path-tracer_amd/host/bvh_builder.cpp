@@ -1,18 +1,32 @@
 // Host BVH builder: binned SAH over centroid buckets, two-triangle leaves, right-first flattening into the
 // 64 B two-box node + Woop float4 stream the device upload expects.  The output is byte-identical to what the
-// reference's builder produces (src/bvh.cu:100-294); the work is organised differently:
-//   * triangle boxes and centroids are computed once, and the build permutes an index array instead of the triangles;
-//   * subtrees above a size threshold are built as independent tasks on other threads and spliced (the preorder
-//     layout stores subtree sizes, so splicing is concatenation).
+// reference's builder produces (src/bvh.cu:100-294) and does not depend on the thread count; the work is organised
+// differently:
+//   * triangle boxes are computed once and permuted together with an index array, so that every pass over a range
+//     streams through memory; centroids are recomputed from the boxes (the same (lo + hi) / 2 every time);
+//   * the top of the tree (ranges of kParMin triangles and more) is built node by node with every pass over the range
+//     -- bounds, bucket histogram, partition -- split over all threads.  The partition reproduces the element order of
+//     the sequential two-pointer partition: that algorithm swaps the k-th misplaced element from the left with the
+//     k-th misplaced element from the right, which can be done for all k at once;
+//   * the ranges below are independent subtrees, built one per task;
+//   * the position of every node and leaf in the flattened buffers follows from subtree sizes alone, so the same
+//     subtrees are flattened (and their triangles Woop-transformed) in parallel, straight into the output buffers.
+// Reductions keep the sequential result bit for bit: min/max folds pick the later of two equal values (+0/-0), and
+// chunk results are merged in chunk order.
 // No fused multiply-adds anywhere in this file (the Makefile passes -ffp-contract=off): bucket choice depends on
 // float rounding.
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <future>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "host_internal.h"
@@ -23,6 +37,8 @@ namespace {
 
 constexpr float kEps = 0.001f;      // reference src/common.h:17
 constexpr int kBuckets = 12;        // reference src/bvh.cu:13
+constexpr uint32_t kParMin = 1u << 16;      // ranges at least this long are split with all threads
+constexpr uint32_t kChunkMin = 1u << 13;    // smallest piece of a range handed to one thread
 
 struct Bounds {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};       // reference src/aabb.cpp:8
@@ -55,51 +71,211 @@ struct Bounds {
     }
 };
 
+// Uninitialised storage for plain data (a std::vector would fill gigabytes on one thread first).
+template <class T>
+struct Array {
+    T *p;
+    explicit Array(uint64_t n) : p((T *)std::malloc(std::max<uint64_t>(n, 1) * sizeof(T))) {}
+    ~Array() { std::free(p); }
+    Array(const Array &) = delete;
+    Array &operator=(const Array &) = delete;
+    T &operator[](uint64_t i) { return p[i]; }
+    const T &operator[](uint64_t i) const { return p[i]; }
+};
+
+// Workers that run fn(0..n-1) together with the calling thread.  One job at a time.
+class Pool {
+public:
+    explicit Pool(int threads)
+    {
+        for (int i = 1; i < threads; i++) workers_.emplace_back([this] { work(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_job_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    int threads() const { return (int)workers_.size() + 1; }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 0) return;
+        if (workers_.empty() || n == 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            busy_ = (int)workers_.size();
+            gen_++;
+        }
+        cv_job_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m_);
+        cv_done_.wait(g, [this] { return busy_ == 0; });
+    }
+
+private:
+    void drain()
+    {
+        for (int i; (i = next_.fetch_add(1)) < n_;) (*fn_)(i);
+    }
+    void work()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_job_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                busy_--;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_job_, cv_done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int n_ = 0, busy_ = 0;
+    std::atomic<int> next_{0};
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// A subtree in preorder: the left child of node i is i + 1, the right child i + 1 + [i + 1].subtree.
 struct TreeNode {
     Bounds box;
     uint32_t first = 0;        // leaf: position in the order array
     uint32_t count = 0;        // leaf: 1 or 2 triangles; interior: 0
-    uint32_t subtree = 1;      // nodes in this subtree including this one; right child = self + 1 + left.subtree
+    uint32_t subtree = 1;      // nodes in this subtree including this one
+    uint32_t ntris = 0;        // triangles below this node
+};
+
+// interior nodes and float4 entries (3 per triangle + 1 terminator per leaf) a subtree takes in the flattened buffers
+inline uint64_t interior_of(uint32_t subtree) { return (subtree - 1) / 2; }
+inline uint64_t float4s_of(uint32_t subtree, uint64_t ntris) { return 3 * ntris + (subtree + 1) / 2; }
+
+// A node of the tree top: either an interior node with two TopNode children or a whole subtree built by one task.
+struct TopNode {
+    int left = -1, right = -1;
+    int task = -1;
+    Bounds box;
+    uint32_t subtree = 0;
+    uint32_t ntris = 0;
+    uint32_t leaf_count = 0;   // > 0: the subtree is a single leaf
+};
+
+struct Task {
+    uint32_t start, end, depth;
+    std::vector<TreeNode> nodes;
+    uint32_t max_depth = 0;
+    uint64_t node_off = 0, tri_off = 0;     // where its root lands in the flattened buffers
 };
 
 struct Builder {
     const float *verts;
-    std::vector<Bounds> tri_box;
-    std::vector<float> centroid;        // 3 per triangle
-    std::vector<uint32_t> order;
-    int spawn_budget;
-    std::atomic<int> live_tasks{0};
+    Pool &pool;
+    Array<Bounds> pbox;                 // box of the triangle at each position of the order array
+    Array<uint32_t> order;
+    std::vector<uint8_t> side;          // per position of the range being split: its bucket
+    std::vector<uint32_t> bad_l, bad_r; // positions of misplaced elements of the range being split
+    std::vector<TopNode> top;
+    std::vector<Task> tasks;
+    uint32_t top_depth = 0;
 
-    explicit Builder(const float *v, uint64_t n, int threads) : verts(v), tri_box(n), centroid(3 * n), order(n)
+    Builder(const float *v, uint64_t n, Pool &p) : verts(v), pool(p), pbox(n), order(n)
     {
-        spawn_budget = threads > 1 ? threads - 1 : 0;
-        for (uint64_t i = 0; i < n; i++) {
-            const float *p = v + 9 * i;
-            Bounds b;
-            for (int a = 0; a < 3; a++) {
-                // reference src/bvh.cuh:39-49: min/max of the three vertices, flat boxes padded by EPSILON
-                float lo = p[a] < p[3 + a] ? p[a] : p[3 + a];
-                lo = lo < p[6 + a] ? lo : p[6 + a];
-                float hi = p[a] > p[3 + a] ? p[a] : p[3 + a];
-                hi = hi > p[6 + a] ? hi : p[6 + a];
-                if (hi - lo == 0) hi += kEps;
-                b.lo[a] = lo;
-                b.hi[a] = hi;
-                centroid[3 * i + a] = (lo + hi) / 2;        // reference src/aabb.cpp:27-30
+        if (!pbox.p || !order.p) return;
+        const int chunks = pieces(n);
+        pool.run(chunks, [&](int c) {
+            const uint64_t b = n * c / chunks, e = n * (c + 1) / chunks;
+            for (uint64_t i = b; i < e; i++) {
+                const float *q = v + 9 * i;
+                Bounds bx;
+                for (int a = 0; a < 3; a++) {
+                    // reference src/bvh.cuh:39-49: min/max of the three vertices, flat boxes padded by EPSILON
+                    float lo = q[a] < q[3 + a] ? q[a] : q[3 + a];
+                    lo = lo < q[6 + a] ? lo : q[6 + a];
+                    float hi = q[a] > q[3 + a] ? q[a] : q[3 + a];
+                    hi = hi > q[6 + a] ? hi : q[6 + a];
+                    if (hi - lo == 0) hi += kEps;
+                    bx.lo[a] = lo;
+                    bx.hi[a] = hi;
+                }
+                pbox[i] = bx;
+                order[i] = (uint32_t)i;
             }
-            tri_box[i] = b;
-            order[i] = (uint32_t)i;
-        }
+        });
     }
 
-    int bucket(uint32_t tri, const Bounds &cb, int axis) const      // reference src/bvh.cu:87-90,142-143
+    int pieces(uint64_t n) const
     {
-        const float f = kBuckets * (centroid[3 * (size_t)tri + axis] - cb.lo[axis]) / (cb.hi[axis] - cb.lo[axis]);
+        const uint64_t most = (uint64_t)pool.threads() * 4;
+        return (int)std::max<uint64_t>(1, std::min(most, n / kChunkMin));
+    }
+
+    static float centre(const Bounds &b, int axis) { return (b.lo[axis] + b.hi[axis]) / 2; }     // reference src/aabb.cpp:27-30
+    static void grow_centre(Bounds &c, const Bounds &b)
+    {
+        const float p[3] = {centre(b, 0), centre(b, 1), centre(b, 2)};
+        c.grow(p);
+    }
+    void swap_positions(uint32_t i, uint32_t j)
+    {
+        std::swap(order[i], order[j]);
+        std::swap(pbox[i], pbox[j]);
+    }
+
+    int bucket(uint32_t pos, const Bounds &cb, int axis) const      // reference src/bvh.cu:87-90,142-143
+    {
+        const float f = kBuckets * (centre(pbox[pos], axis) - cb.lo[axis]) / (cb.hi[axis] - cb.lo[axis]);
         int b = (int)(size_t)f;
         if (b == kBuckets) b--;
         return b;
     }
 
+    // reference src/bvh.cu:150-173: cost of each of the 11 splits, first minimum wins.  The reference folds the boxes
+    // of both sides anew for every split; here the right sides come from one sweep from the top.  That fold runs in
+    // the opposite order, which can only change the sign of a zero bound, and the areas cannot see that.
+    static size_t best_split_of(const Bounds *bbox, const size_t *bcount, const Bounds &all)
+    {
+        float right_area[kBuckets];
+        size_t right_n[kBuckets];
+        Bounds b1;
+        size_t n1 = 0;
+        for (int i = kBuckets - 1; i > 0; i--) {
+            b1.grow(bbox[i]);
+            n1 += bcount[i];
+            right_area[i - 1] = b1.area();
+            right_n[i - 1] = n1;
+        }
+        const float whole = all.area();
+        float best = 0;
+        size_t best_split = 0;
+        Bounds b0;
+        size_t n0 = 0;
+        for (int i = 0; i < kBuckets - 1; i++) {
+            b0.grow(bbox[i]);
+            n0 += bcount[i];
+            const float cost = (n0 * b0.area() + right_n[i] * right_area[i]) / whole + 1;
+            if (i == 0 || cost < best) { best = cost; best_split = (size_t)i; }
+        }
+        return best_split;
+    }
+
+    // ---- one subtree on one thread ---------------------------------------------------------------------------------
     void build(uint32_t start, uint32_t end, std::vector<TreeNode> &out, uint32_t depth, uint32_t &max_depth)
     {
         const size_t self = out.size();
@@ -107,25 +283,26 @@ struct Builder {
         if (depth > max_depth) max_depth = depth;
         Bounds all, cents;
         for (uint32_t i = start; i < end; i++) {
-            all.grow(tri_box[order[i]]);
-            cents.grow(&centroid[3 * (size_t)order[i]]);
+            all.grow(pbox[i]);
+            grow_centre(cents, pbox[i]);
         }
         const int axis = cents.longest_axis();
         const uint32_t n = end - start;
+        out[self].ntris = n;
         if (n == 1) {
             out[self].first = start;
             out[self].count = 1;
-            out[self].box = tri_box[order[start]];
+            out[self].box = pbox[start];
             return;
         }
         if (n == 2) {
             // reference src/bvh.cu:123-131: the pair is ordered along the axis
-            const float ca = centroid[3 * (size_t)order[start] + axis], cb = centroid[3 * (size_t)order[start + 1] + axis];
-            if (!(ca < cb)) std::swap(order[start], order[start + 1]);
+            const float ca = centre(pbox[start], axis), cb = centre(pbox[start + 1], axis);
+            if (!(ca < cb)) swap_positions(start, start + 1);
             out[self].first = start;
             out[self].count = 2;
-            Bounds b = tri_box[order[start]];
-            b.grow(tri_box[order[start + 1]]);
+            Bounds b = pbox[start];
+            b.grow(pbox[start + 1]);
             out[self].box = b;
             return;
         }
@@ -137,72 +314,151 @@ struct Builder {
             Bounds bbox[kBuckets];
             size_t bcount[kBuckets] = {};
             for (uint32_t i = start; i < end; i++) {
-                const int b = bucket(order[i], cents, axis);
+                const int b = bucket(i, cents, axis);
                 bcount[b]++;
-                bbox[b].grow(tri_box[order[i]]);
+                bbox[b].grow(pbox[i]);
             }
-            // reference src/bvh.cu:150-173: cost of each of the 11 splits, first minimum wins
-            float best = 0;
-            size_t best_split = 0;
-            for (int i = 0; i < kBuckets - 1; i++) {
-                Bounds b0, b1;
-                size_t n0 = 0, n1 = 0;
-                for (int j = 0; j <= i; j++) { b0.grow(bbox[j]); n0 += bcount[j]; }
-                for (int j = i + 1; j < kBuckets; j++) { b1.grow(bbox[j]); n1 += bcount[j]; }
-                const float cost = (n0 * b0.area() + n1 * b1.area()) / all.area() + 1;
-                if (i == 0 || cost < best) { best = cost; best_split = (size_t)i; }
-            }
+            const size_t best_split = best_split_of(bbox, bcount, all);
             // in-place two-pointer partition, element order as std::partition leaves it (reference src/bvh.cu:176-184)
             uint32_t lo = start, hi = end;
-            auto left_side = [&](uint32_t t) { return (size_t)bucket(t, cents, axis) <= best_split; };
+            auto left_side = [&](uint32_t pos) { return (size_t)bucket(pos, cents, axis) <= best_split; };
             for (;;) {
-                while (lo != hi && left_side(order[lo])) lo++;
+                while (lo != hi && left_side(lo)) lo++;
                 if (lo == hi) break;
                 hi--;
-                while (lo != hi && !left_side(order[hi])) hi--;
+                while (lo != hi && !left_side(hi)) hi--;
                 if (lo == hi) break;
-                std::swap(order[lo], order[hi]);
+                swap_positions(lo, hi);
                 lo++;
             }
             mid = lo;
             if (mid == start || mid == end) mid = start + n / 2;
         }
 
-        // children: the left subtree may run on another thread, results are concatenated in preorder
-        constexpr uint32_t kTaskMin = 1u << 15;
-        bool spawned = false;
-        std::future<std::pair<std::vector<TreeNode>, uint32_t>> fut;
-        if (spawn_budget > 0 && (mid - start) >= kTaskMin && (end - mid) >= kTaskMin) {
-            if (live_tasks.fetch_add(1) < spawn_budget) {
-                spawned = true;
-                fut = std::async(std::launch::async, [this, start, mid, depth]() {
-                    std::vector<TreeNode> sub;
-                    uint32_t md = 0;
-                    build(start, mid, sub, depth + 1, md);
-                    live_tasks.fetch_sub(1);
-                    return std::make_pair(std::move(sub), md);
-                });
-            } else {
-                live_tasks.fetch_sub(1);
-            }
-        }
-        if (spawned) {
-            std::vector<TreeNode> right;
-            uint32_t mdr = 0;
-            build(mid, end, right, depth + 1, mdr);
-            auto left = fut.get();
-            max_depth = std::max(max_depth, std::max(mdr, left.second));
-            out.insert(out.end(), left.first.begin(), left.first.end());
-            out.insert(out.end(), right.begin(), right.end());
-        } else {
-            build(start, mid, out, depth + 1, max_depth);
-            build(mid, end, out, depth + 1, max_depth);
-        }
+        build(start, mid, out, depth + 1, max_depth);
+        build(mid, end, out, depth + 1, max_depth);
         const size_t l = self + 1, r = l + out[l].subtree;
         out[self].subtree = 1 + out[l].subtree + out[r].subtree;
         Bounds b = out[l].box;
         b.grow(out[r].box);
         out[self].box = b;
+    }
+
+    // ---- the tree top: one node at a time, every pass over the range on all threads -------------------------------
+    // Splits [start, end) exactly as build() does and returns the split position.
+    uint32_t split_parallel(uint32_t start, uint32_t end)
+    {
+        const uint32_t n = end - start;
+        const int chunks = pieces(n);
+        auto lo_of = [&](int c) { return start + (uint32_t)((uint64_t)n * c / chunks); };
+
+        std::vector<Bounds> c_all(chunks), c_cent(chunks);
+        pool.run(chunks, [&](int c) {
+            Bounds a, ce;
+            for (uint32_t i = lo_of(c), e = lo_of(c + 1); i < e; i++) {
+                a.grow(pbox[i]);
+                grow_centre(ce, pbox[i]);
+            }
+            c_all[c] = a;
+            c_cent[c] = ce;
+        });
+        Bounds all, cents;
+        for (int c = 0; c < chunks; c++) { all.grow(c_all[c]); cents.grow(c_cent[c]); }
+        const int axis = cents.longest_axis();
+        if (!(cents.hi[axis] - cents.lo[axis] > 0.0f)) return start + n / 2;
+
+        struct Hist { Bounds box[kBuckets]; size_t count[kBuckets] = {}; };
+        std::vector<Hist> hist(chunks);
+        pool.run(chunks, [&](int c) {
+            Hist &h = hist[c];
+            for (uint32_t i = lo_of(c), e = lo_of(c + 1); i < e; i++) {
+                const int b = bucket(i, cents, axis);
+                side[i] = (uint8_t)b;
+                h.count[b]++;
+                h.box[b].grow(pbox[i]);
+            }
+        });
+        Bounds bbox[kBuckets];
+        size_t bcount[kBuckets] = {};
+        for (int c = 0; c < chunks; c++)
+            for (int b = 0; b < kBuckets; b++) { bbox[b].grow(hist[c].box[b]); bcount[b] += hist[c].count[b]; }
+        const size_t best_split = best_split_of(bbox, bcount, all);
+
+        size_t nleft = 0;
+        for (size_t b = 0; b <= best_split; b++) nleft += bcount[b];
+        const uint32_t mid = start + (uint32_t)nleft;
+        if (mid == start || mid == end) return start + n / 2;      // nothing is out of place: no swaps either way
+
+        // The two-pointer partition swaps the k-th element from the left that belongs right with the k-th element
+        // from the right that belongs left, until the pointers meet at mid.
+        std::vector<uint32_t> n_l(chunks + 1, 0), n_r(chunks + 1, 0);
+        pool.run(chunks, [&](int c) {
+            uint32_t l = 0, r = 0;
+            for (uint32_t i = lo_of(c), e = lo_of(c + 1); i < e; i++) {
+                const bool left = side[i] <= best_split;
+                if (i < mid) l += !left;
+                else r += left;
+            }
+            n_l[c + 1] = l;
+            n_r[c + 1] = r;
+        });
+        for (int c = 0; c < chunks; c++) { n_l[c + 1] += n_l[c]; n_r[c + 1] += n_r[c]; }
+        const uint32_t K = n_l[chunks];
+        pool.run(chunks, [&](int c) {
+            uint32_t l = n_l[c], r = n_r[c];
+            for (uint32_t i = lo_of(c), e = lo_of(c + 1); i < e; i++) {
+                const bool left = side[i] <= best_split;
+                if (i < mid) { if (!left) bad_l[l++] = i; }
+                else if (left) bad_r[r++] = i;
+            }
+        });
+        const int sw = pieces(K);
+        pool.run(sw, [&](int c) {
+            for (uint32_t k = (uint32_t)((uint64_t)K * c / sw), e = (uint32_t)((uint64_t)K * (c + 1) / sw); k < e; k++)
+                swap_positions(bad_l[k], bad_r[K - 1 - k]);
+        });
+        return mid;
+    }
+
+    int build_top(uint32_t start, uint32_t end, uint32_t depth)
+    {
+        const int self = (int)top.size();
+        top.emplace_back();
+        const uint32_t n = end - start;
+        if (n < kParMin || pool.threads() == 1) {
+            top[self].task = (int)tasks.size();
+            tasks.push_back(Task{start, end, depth, {}, 0, 0, 0});
+            return self;
+        }
+        if (depth > top_depth) top_depth = depth;
+        const uint32_t mid = split_parallel(start, end);
+        const int l = build_top(start, mid, depth + 1);
+        const int r = build_top(mid, end, depth + 1);
+        top[self].left = l;
+        top[self].right = r;
+        return self;
+    }
+
+    // sizes and boxes of the top nodes, children first (after the tasks have run)
+    void finish_top(int i)
+    {
+        TopNode &t = top[i];
+        if (t.task >= 0) {
+            const TreeNode &root = tasks[t.task].nodes[0];
+            t.box = root.box;
+            t.subtree = root.subtree;
+            t.ntris = root.ntris;
+            t.leaf_count = root.count;
+            return;
+        }
+        finish_top(t.left);
+        finish_top(t.right);
+        const TopNode &l = top[t.left], &r = top[t.right];
+        t.subtree = 1 + l.subtree + r.subtree;
+        t.ntris = l.ntris + r.ntris;
+        Bounds b = l.box;
+        b.grow(r.box);
+        t.box = b;
     }
 };
 
@@ -251,6 +507,111 @@ void woop_rows(const float *v, float out[12])
 
 inline float bits_to_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+
+
+// Writes the flattened form (reference src/bvh.cu:234-294) straight into the output buffers.  The reference emits
+// nodes depth first with the right child visited first, and a node's leaf children when the node itself is emitted
+// (left leaf, then right leaf); a subtree therefore occupies one contiguous run of nodes and one of float4s, and the
+// position of everything follows from subtree sizes.
+struct Flattener {
+    const Builder &b;
+    float *gnodes;
+    float *gtris;
+    uint32_t *gids;
+
+    uint32_t emit_leaf(uint32_t first, uint32_t count, uint64_t at) const
+    {
+        for (uint32_t k = 0; k < count; k++) {
+            const uint32_t tri = b.order[first + k];
+            woop_rows(b.verts + 9 * (size_t)tri, gtris + 4 * (at + 3 * k));
+            uint32_t *id = gids + at + 3 * k;
+            id[0] = tri; id[1] = PT_PRIM_MISS; id[2] = PT_PRIM_MISS;
+        }
+        const float term = bits_to_float(0x80000000u);
+        float *t = gtris + 4 * (at + 3 * (uint64_t)count);
+        t[0] = t[1] = t[2] = t[3] = term;
+        gids[at + 3 * (uint64_t)count] = PT_PRIM_MISS;
+        return ~(uint32_t)at;
+    }
+
+    static void boxes(float g[16], const Bounds &l, const Bounds &r)
+    {
+        const float v[12] = {l.lo[0], l.hi[0], l.lo[1], l.hi[1], r.lo[0], r.hi[0], r.lo[1], r.hi[1],
+                             l.lo[2], l.hi[2], r.lo[2], r.hi[2]};
+        std::memcpy(g, v, sizeof v);
+        g[12] = g[13] = g[14] = g[15] = 0.0f;
+    }
+
+    // one task's subtree, its root an interior node that lands at (node_off, tri_off)
+    void subtree(const std::vector<TreeNode> &tree, uint64_t node_off, uint64_t tri_off) const
+    {
+        struct Todo { uint32_t node; uint64_t node_off, tri_off; };
+        std::vector<Todo> todo;
+        todo.push_back({0, node_off, tri_off});
+        while (!todo.empty()) {
+            const Todo e = todo.back();
+            todo.pop_back();
+            const uint32_t li = e.node + 1, ri = li + tree[li].subtree;
+            const TreeNode &l = tree[li], &r = tree[ri];
+            float g[16];
+            boxes(g, l.box, r.box);
+            uint64_t toff = e.tri_off, noff = e.node_off + 1;
+            if (l.count) { g[12] = bits_to_float(emit_leaf(l.first, l.count, toff)); toff += 3 * l.count + 1; }
+            if (r.count) { g[13] = bits_to_float(emit_leaf(r.first, r.count, toff)); toff += 3 * r.count + 1; }
+            if (!r.count) {
+                g[13] = bits_to_float((uint32_t)noff);
+                todo.push_back({ri, noff, toff});
+                noff += interior_of(r.subtree);
+                toff += float4s_of(r.subtree, r.ntris);
+            }
+            if (!l.count) {
+                g[12] = bits_to_float((uint32_t)noff);
+                todo.push_back({li, noff, toff});
+            }
+            std::memcpy(gnodes + 16 * e.node_off, g, sizeof g);
+        }
+    }
+
+    // the tree top; subtrees built by tasks only get their position here
+    void top(int i, uint64_t node_off, uint64_t tri_off, std::vector<Task> &tasks) const
+    {
+        const TopNode &t = b.top[i];
+        if (t.task >= 0) {
+            tasks[t.task].node_off = node_off;
+            tasks[t.task].tri_off = tri_off;
+            return;
+        }
+        const TopNode &l = b.top[t.left], &r = b.top[t.right];
+        float g[16];
+        boxes(g, l.box, r.box);
+        uint64_t toff = tri_off, noff = node_off + 1;
+        if (l.leaf_count) {
+            g[12] = bits_to_float(emit_leaf(tasks[l.task].nodes[0].first, l.leaf_count, toff));
+            toff += 3 * l.leaf_count + 1;
+        }
+        if (r.leaf_count) {
+            g[13] = bits_to_float(emit_leaf(tasks[r.task].nodes[0].first, r.leaf_count, toff));
+            toff += 3 * r.leaf_count + 1;
+        }
+        if (!r.leaf_count) {
+            g[13] = bits_to_float((uint32_t)noff);
+            top(t.right, noff, toff, tasks);
+            noff += interior_of(r.subtree);
+            toff += float4s_of(r.subtree, r.ntris);
+        }
+        if (!l.leaf_count) {
+            g[12] = bits_to_float((uint32_t)noff);
+            top(t.left, noff, toff, tasks);
+        }
+        std::memcpy(gnodes + 16 * node_off, g, sizeof g);
+    }
+};
+
+double seconds_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 }   // namespace
 
 int bvh_build(const float *verts, uint64_t ntris, int threads, pth_bvh *out)
@@ -259,78 +620,68 @@ int bvh_build(const float *verts, uint64_t ntris, int threads, pth_bvh *out)
     if (!verts) return set_error("pth_bvh_build: verts is NULL");
     if (ntris < 3) return set_error("pth_bvh_build: at least 3 triangles are needed (the root must be an interior node)");
     if (ntris >= (1ull << 29)) return set_error("pth_bvh_build: too many triangles");
+    const bool timing = std::getenv("PTH_BUILD_TIMING") != nullptr;      // phase times on stderr
+    const auto t0 = std::chrono::steady_clock::now();
 
-    Builder b(verts, ntris, threads);
-    std::vector<TreeNode> tree;
-    tree.reserve(2 * ntris);
-    uint32_t max_depth = 0;
-    b.build(0, (uint32_t)ntris, tree, 0, max_depth);
-
-    // flatten: depth-first with the right child visited first, parents patched when a child is emitted
-    // (reference src/bvh.cu:234-294)
-    std::vector<float> gnodes;
-    gnodes.reserve(16 * ntris);
-    std::vector<float> gtris;
-    gtris.reserve(16 * ntris + 16);
-    std::vector<uint32_t> gids;
-    gids.reserve(4 * ntris + 4);
-    gtris.assign(4, 0.0f);
-    gids.push_back(PT_PRIM_MISS);
-    uint64_t leaves = 0;
-
-    auto emit_leaf = [&](const TreeNode &leaf) -> uint32_t {
-        const uint32_t ref = ~(uint32_t)(gtris.size() / 4);
-        for (uint32_t k = 0; k < leaf.count; k++) {
-            const uint32_t tri = b.order[leaf.first + k];
-            float w[12];
-            woop_rows(verts + 9 * (size_t)tri, w);
-            gtris.insert(gtris.end(), w, w + 12);
-            gids.push_back(tri); gids.push_back(PT_PRIM_MISS); gids.push_back(PT_PRIM_MISS);
-        }
-        const float term = bits_to_float(0x80000000u);
-        gtris.insert(gtris.end(), {term, term, term, term});
-        gids.push_back(PT_PRIM_MISS);
-        leaves++;
-        return ref;
-    };
-
-    struct Todo { uint32_t node; uint32_t parent; bool left; };
-    std::vector<Todo> todo;
-    todo.push_back({0, 0, false});
-    while (!todo.empty()) {
-        const Todo e = todo.back();
-        todo.pop_back();
-        const uint32_t li = e.node + 1, ri = li + tree[li].subtree;
-        const TreeNode &l = tree[li], &r = tree[ri];
-        const uint32_t me = (uint32_t)(gnodes.size() / 16);
-        float g[16] = {l.box.lo[0], l.box.hi[0], l.box.lo[1], l.box.hi[1], r.box.lo[0], r.box.hi[0], r.box.lo[1],
-                       r.box.hi[1], l.box.lo[2], l.box.hi[2], r.box.lo[2], r.box.hi[2], 0, 0, 0, 0};
-        if (e.node != 0) gnodes[(size_t)e.parent * 16 + (e.left ? 12 : 13)] = bits_to_float(me);
-        if (l.count == 0) todo.push_back({li, me, true});
-        else g[12] = bits_to_float(emit_leaf(l));
-        if (r.count == 0) todo.push_back({ri, me, false});
-        else g[13] = bits_to_float(emit_leaf(r));
-        gnodes.insert(gnodes.end(), g, g + 16);
+    Pool pool(threads < 1 ? 1 : threads);
+    Builder b(verts, ntris, pool);
+    if (!b.pbox.p || !b.order.p) return set_error("pth_bvh_build: out of memory");
+    if (pool.threads() > 1 && ntris >= kParMin) {
+        b.side.resize(ntris);
+        b.bad_l.resize(ntris / 2 + 1);
+        b.bad_r.resize(ntris / 2 + 1);
     }
+    const double t_prep = seconds_since(t0);
+    const int root = b.build_top(0, (uint32_t)ntris, 0);
+    const double t_top = seconds_since(t0);
 
-    out->num_nodes = gnodes.size() / 16;
-    out->num_tri_float4 = gtris.size() / 4;
+    // the subtrees, largest first
+    std::vector<int> by_size(b.tasks.size());
+    for (size_t i = 0; i < by_size.size(); i++) by_size[i] = (int)i;
+    std::sort(by_size.begin(), by_size.end(), [&](int x, int y) {
+        const uint32_t nx = b.tasks[x].end - b.tasks[x].start, ny = b.tasks[y].end - b.tasks[y].start;
+        return nx != ny ? nx > ny : x < y;
+    });
+    pool.run((int)by_size.size(), [&](int k) {
+        Task &t = b.tasks[by_size[k]];
+        t.nodes.reserve(2 * (size_t)(t.end - t.start));
+        b.build(t.start, t.end, t.nodes, t.depth, t.max_depth);
+    });
+    b.finish_top(root);
+    uint32_t max_depth = b.top_depth;
+    for (const Task &t : b.tasks) max_depth = std::max(max_depth, t.max_depth);
+    const double t_sub = seconds_since(t0);
+
+    const TopNode &rt = b.top[root];
+    const uint64_t num_nodes = interior_of(rt.subtree);
+    const uint64_t num_f4 = 1 + float4s_of(rt.subtree, rt.ntris);       // float4 #0 is a zero pad (src/bvh.cu:240)
+    out->num_nodes = num_nodes;
+    out->num_tri_float4 = num_f4;
     out->num_tris = ntris;
-    out->num_leaves = leaves;
+    out->num_leaves = (rt.subtree + 1) / 2;
     out->max_depth = max_depth;
-    out->nodes = (float *)std::malloc(gnodes.size() * sizeof(float));
+    out->nodes = (float *)std::malloc(num_nodes * 16 * sizeof(float));
     // two float4 of zero padding: a reader in the reference's style fetches three float4 before it looks for the
     // terminator (src/bvh.cuh:174-181)
-    out->tris = (float *)std::calloc(gtris.size() + 8, sizeof(float));
-    out->prim_ids = (uint32_t *)std::malloc(gids.size() * sizeof(uint32_t));
+    out->tris = (float *)std::calloc((num_f4 + 2) * 4, sizeof(float));
+    out->prim_ids = (uint32_t *)std::malloc(num_f4 * sizeof(uint32_t));
     if (!out->nodes || !out->tris || !out->prim_ids) {
         std::free(out->nodes); std::free(out->tris); std::free(out->prim_ids);
         std::memset(out, 0, sizeof *out);
         return set_error("pth_bvh_build: out of memory");
     }
-    std::memcpy(out->nodes, gnodes.data(), gnodes.size() * sizeof(float));
-    std::memcpy(out->tris, gtris.data(), gtris.size() * sizeof(float));
-    std::memcpy(out->prim_ids, gids.data(), gids.size() * sizeof(uint32_t));
+    out->prim_ids[0] = PT_PRIM_MISS;
+
+    const Flattener f{b, out->nodes, out->tris, out->prim_ids};
+    f.top(root, 0, 1, b.tasks);
+    pool.run((int)by_size.size(), [&](int k) {
+        const Task &t = b.tasks[by_size[k]];
+        if (t.nodes[0].count == 0) f.subtree(t.nodes, t.node_off, t.tri_off);   // a single leaf was emitted by its parent
+    });
+    if (timing)
+        std::fprintf(stderr, "pth_bvh_build: %llu triangles, %d threads: prepare %.2f s, top %.2f s (%zu subtrees), "
+                     "subtrees %.2f s, flatten %.2f s\n", (unsigned long long)ntris, pool.threads(), t_prep,
+                     t_top - t_prep, b.tasks.size(), t_sub - t_top, seconds_since(t0) - t_sub);
     return 0;
 }
 

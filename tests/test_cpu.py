@@ -129,14 +129,42 @@ def test_host_bvh_equals_oracle(pkg, name, threads):
 
 
 def test_host_bvh_parallel_build_equals_serial(pkg):
-    """A mesh large enough for the task-parallel path (subtrees of >= 32,768 triangles go to other threads)."""
+    """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
+    bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""
     tris = S.knot_mesh(pkg)
     rng = np.random.default_rng(0)
     big = np.concatenate([tris + rng.uniform(-3, 3, size=(1, 1, 3)).astype(np.float32) for _ in range(12)])
     a = pkg.bvh_build(big, threads=1)
-    b = pkg.bvh_build(big, threads=8)
+    for threads in (2, 3, 8):
+        b = pkg.bvh_build(big, threads=threads)
+        for k in ("nodes", "tris", "prim_ids"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (threads, k)
+        assert a["max_depth"] == b["max_depth"] and a["num_leaves"] == b["num_leaves"]
+
+
+@pytest.mark.parametrize("case", ["outliers", "coincident", "signed_zero"])
+def test_host_bvh_parallel_top_edge_cases(pkg, case):
+    """Shapes of the tree top the parallel path has to get right, against the oracle's sequential builder: a split
+    that leaves a single triangle on one side (a leaf directly below a top node), a large range of coincident
+    centroids (median fallback at the top) and boxes that touch +0 and -0 (min/max ties must pick as a fold does)."""
+    tris = S.knot_mesh(pkg)
+    rng = np.random.default_rng(1)
+    big = np.concatenate([tris + rng.uniform(-2, 2, size=(1, 1, 3)).astype(np.float32) for _ in range(8)])
+    if case == "outliers":
+        far = np.array([[[900, 0, 0], [901, 0, 0], [900, 1, 0]], [[-900, 5, 0], [-901, 5, 0], [-900, 6, 0]]], np.float32)
+        big = np.concatenate([far[:1], big, far[1:]])
+    elif case == "coincident":
+        same = np.repeat(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32), 70000, axis=0)
+        big = np.concatenate([same, big[:5000]])
+    else:
+        big = big.copy()
+        big[::7, :, 0] = np.where(big[::7, :, 0] > 0, np.float32(0.0), np.float32(-0.0))
+        big[3::11, :, 1] = np.float32(-0.0)
+    a = pkg.bvh_build(big, threads=4)
+    b = O.bvh_build(big)
     for k in ("nodes", "tris", "prim_ids"):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert a["max_depth"] == b["max_depth"] and a["num_leaves"] == b["num_leaves"]
 
 
 def test_host_bvh_rejects_tiny_meshes(pkg):
