@@ -138,6 +138,7 @@ def hip_lib():
         L.pt_film_bind.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.pt_film_clear.argtypes = [C.c_void_p]
         L.pt_film_download.argtypes = [C.c_void_p, C.c_void_p]
+        L.pt_film_tonemap16.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.pt_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
         L.pt_env_is_packed.argtypes = [C.c_void_p]
         L.pt_stream.restype = C.c_void_p
@@ -360,6 +361,11 @@ class Context:
     def film_download(self):
         out = np.zeros(self.film_shape, dtype=np.float32)
         self._check(self._L.pt_film_download(self._h, _ptr(out)))
+        return out
+
+    def film_tonemap16(self, exposure=2.0, gamma=2.2):
+        out = np.zeros(self.film_shape, dtype=np.uint16)
+        self._check(self._L.pt_film_tonemap16(self._h, exposure, gamma, _ptr(out)))
         return out
 
     def render(self, spp_begin, spp_count, spp_total, seed=0):

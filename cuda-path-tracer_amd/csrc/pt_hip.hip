@@ -409,6 +409,16 @@ __global__ __launch_bounds__(kBlock) void k_hit_expand(DScene sc, const float4 *
     }
 }
 
+// film -> 16-bit samples: c' = (1 - exp(-c * exposure)) ^ (1 / gamma), truncated (reference src/image.cpp:12-33)
+__global__ __launch_bounds__(kBlock) void k_tonemap16(const float *__restrict__ film, uint64_t n, float exposure,
+                                                      float inv_gamma, uint16_t *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+        const float c = powf(1.0f - expf(-film[i] * exposure), inv_gamma);
+        out[i] = (uint16_t)(65535 * c);
+    }
+}
+
 // camera rays of one sample index in film-pixel order (parity check of the generate stage)
 __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, uint32_t sample, uint32_t seed0,
                                                     uint32_t seed1, float4 *__restrict__ ro, float4 *__restrict__ rd)
@@ -740,7 +750,7 @@ int pt_ctx_create(int device, pt_ctx **out)
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
             fail(nullptr, PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));            \
-            delete ctx;                                                                           \
+            pt_ctx_destroy(ctx);                                                                  \
             return PT_ERR_HIP;                                                                    \
         }                                                                                         \
     } while (0)
@@ -1182,6 +1192,25 @@ int pt_film_download(pt_ctx *ctx, float *rgb_out)
     HIPCHK(ctx, hipMemcpyAsync(rgb_out, ctx->film, (size_t)ctx->W * ctx->H * 3 * sizeof(float), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_film_tonemap16(pt_ctx *ctx, float exposure, float gamma, uint16_t *rgb_out)
+{
+    if (!ctx || !rgb_out) return PT_ERR_ARG;
+    if (!ctx->film) return fail(ctx, PT_ERR_STATE, "pt_film_tonemap16: no film bound");
+    if (!(gamma > 0.0f)) return fail(ctx, PT_ERR_ARG, "pt_film_tonemap16: gamma must be positive");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)ctx->W * ctx->H * 3;
+    uint16_t *d16 = nullptr;
+    HIPCHK(ctx, hipMalloc(&d16, n * sizeof(uint16_t)));
+    hipLaunchKernelGGL(k_tonemap16, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->film, n, exposure,
+                       1.0f / gamma, d16);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, d16, n * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d16);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_film_tonemap16: %s", hipGetErrorString(e));
     return PT_OK;
 }
 

@@ -58,17 +58,19 @@ int main(int argc, char **argv)
                 (unsigned long long)st.rays, (unsigned long long)st.paths, (unsigned long long)st.iterations, st.ms_total,
                 st.ms_total > 0 ? st.rays / st.ms_total / 1e3 : 0.0);
 
-    std::vector<float> film(width * height * 3);
-    check(pt_film_download(ctx, film.data()));
-
-    if (const char *e = std::getenv("PT_PFM"))          // PT_PFM=1: also dump the linear film as image_file.pfm
-        if (e[0] == '1' && pth_pfm_write((image_file + ".pfm").c_str(), film.data(), (uint32_t)width, (uint32_t)height) != 0)
-            std::cerr << "Error writing PFM: " << pth_last_error() << "\n";
+    if (const char *e = std::getenv("PT_PFM")) {        // PT_PFM=1: also dump the linear film as image_file.pfm
+        if (e[0] == '1') {
+            std::vector<float> film(width * height * 3);
+            check(pt_film_download(ctx, film.data()));
+            if (pth_pfm_write((image_file + ".pfm").c_str(), film.data(), (uint32_t)width, (uint32_t)height) != 0)
+                std::cerr << "Error writing PFM: " << pth_last_error() << "\n";
+        }
+    }
 
     std::cout << "Saving image...\n";
     t1 = std::chrono::high_resolution_clock::now();
     std::vector<uint16_t> rgb16(width * height * 3);
-    pth_tonemap16(film.data(), width * height, EXPOSURE, GAMMA, rgb16.data());
+    check(pt_film_tonemap16(ctx, EXPOSURE, GAMMA, rgb16.data()));      // tone map on the device, 6 B per pixel come back
     if (pth_png16_write((image_file + ".png").c_str(), rgb16.data(), (uint32_t)width, (uint32_t)height) != 0)
         std::cerr << "Error encoding PNG: " << pth_last_error() << "\n";
     t2 = std::chrono::high_resolution_clock::now();

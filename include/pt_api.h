@@ -167,6 +167,12 @@ int  pt_film_bind(pt_ctx *ctx, uint32_t width, uint32_t height, void *device_fil
 int  pt_film_clear(pt_ctx *ctx);
 int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcpy at reference src/main.cu:40 */
 
+/* Image::tone_map and the 16-bit quantisation of Image::save_png (reference src/image.cpp:12-33) on the device:
+ * rgb_out[width*height*3] = (uint16)(65535 * (1 - exp(-c * exposure)) ^ (1 / gamma)), host buffer.  Half the bytes of
+ * pt_film_download; the device's expf/powf may differ from the host's in the last place, so a sample can differ from
+ * pth_tonemap16's by one step of 65535. */
+int  pt_film_tonemap16(pt_ctx *ctx, float exposure, float gamma, uint16_t *rgb_out);
+
 /* Replaces render_scene (reference src/render.cuh:50, src/render.cu:244-280): accumulates samples
  * [spp_begin, spp_begin+spp_count) of every pixel, each weighted 1/spp_total, into the bound film and returns
  * when the device is done.  Splitting [0, spp_total) over several calls, contexts or GPUs and summing the films

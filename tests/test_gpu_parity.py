@@ -194,6 +194,23 @@ def test_converged_render_matches_oracle(pkg, ctx):
     assert rel_mse <= 1e-3, "relMSE %g" % rel_mse
 
 
+def test_device_tonemap_matches_host(pkg, ctx):
+    """pt_film_tonemap16 against the host tone map (reference src/image.cpp:12-33) on the same film: 16-bit samples
+    equal, except where the device's expf/powf differ from libm's in the last place -- then by one step at most."""
+    W, H, spp = 96, 64, 16
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=4)
+    film = ctx.film_download()
+    dev = ctx.film_tonemap16(2.0, 2.2).astype(np.int64)
+    host = pkg.tonemap16(film, 2.0, 2.2).astype(np.int64).reshape(dev.shape)
+    diff = np.abs(dev - host)
+    assert diff.max() <= 1, "device and host tone map differ by %d steps" % diff.max()
+    assert (diff == 0).mean() >= 0.98, "only %.4f of the samples are equal" % (diff == 0).mean()
+    assert dev.max() > 1000 and dev.min() >= 0
+
+
 def test_render_is_partition_invariant(pkg, ctx):
     """Samples split over two calls (as two GPUs would) sum to the single-call film up to float addition order."""
     W, H, spp = 96, 64, 8
