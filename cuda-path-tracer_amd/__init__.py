@@ -139,6 +139,7 @@ def hip_lib():
         L.pt_film_clear.argtypes = [C.c_void_p]
         L.pt_film_download.argtypes = [C.c_void_p, C.c_void_p]
         L.pt_film_tonemap16.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.pt_film_reduce.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.pt_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
         L.pt_env_is_packed.argtypes = [C.c_void_p]
         L.pt_stream.restype = C.c_void_p
@@ -384,6 +385,14 @@ class Context:
         if rc < 0:
             raise PtError("no scene uploaded")
         return rc == 1
+
+
+def film_reduce(contexts, root=0):
+    """Adds the films of the other contexts to contexts[root]'s (one process driving several GPUs)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = hip_lib().pt_film_reduce(arr, len(contexts), root)
+    if rc != 0:
+        raise PtError("pt_film_reduce: %s" % hip_lib().pt_last_error(contexts[root]._h).decode())
 
 
 def spp_partition(spp_total, world_size, rank):

@@ -409,6 +409,12 @@ __global__ __launch_bounds__(kBlock) void k_hit_expand(DScene sc, const float4 *
     }
 }
 
+// dst += src, element by element (film reduce across contexts)
+__global__ __launch_bounds__(kBlock) void k_film_add(float *__restrict__ dst, const float *__restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) dst[i] += src[i];
+}
+
 // film -> 16-bit samples: c' = (1 - exp(-c * exposure)) ^ (1 / gamma), truncated (reference src/image.cpp:12-33)
 __global__ __launch_bounds__(kBlock) void k_tonemap16(const float *__restrict__ film, uint64_t n, float exposure,
                                                       float inv_gamma, uint16_t *__restrict__ out)
@@ -1211,6 +1217,43 @@ int pt_film_tonemap16(pt_ctx *ctx, float exposure, float gamma, uint16_t *rgb_ou
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d16);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_film_tonemap16: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_film_reduce(pt_ctx *const *ctxs, int n, int root)
+{
+    if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root]) return PT_ERR_ARG;
+    pt_ctx *dst = ctxs[root];
+    if (!dst->film) return fail(dst, PT_ERR_STATE, "pt_film_reduce: no film bound");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !ctxs[i]->film) return fail(dst, PT_ERR_STATE, "pt_film_reduce: context %d has no film", i);
+        if (ctxs[i]->W != dst->W || ctxs[i]->H != dst->H)
+            return fail(dst, PT_ERR_ARG, "pt_film_reduce: context %d has a %ux%u film, the root %ux%u", i, ctxs[i]->W,
+                        ctxs[i]->H, dst->W, dst->H);
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return fail(dst, PT_ERR_ARG, "pt_film_reduce: context %d is listed twice", i);
+    }
+    const uint64_t count = (uint64_t)dst->W * dst->H * 3;
+    // every film must be complete before it is read from another stream
+    for (int i = 0; i < n; i++) {
+        HIPCHK(dst, hipSetDevice(ctxs[i]->device));
+        HIPCHK(dst, hipStreamSynchronize(ctxs[i]->stream));
+    }
+    HIPCHK(dst, hipSetDevice(dst->device));
+    float *staging = nullptr;
+    if (n > 1) HIPCHK(dst, hipMalloc(&staging, count * sizeof(float)));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; i++) {
+        if (i == root) continue;
+        // stream order keeps the one staging buffer safe: copy i+1 starts after add i
+        e = hipMemcpyPeerAsync(staging, dst->device, ctxs[i]->film, ctxs[i]->device, count * sizeof(float), dst->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_film_add, dim3(stream_grid(dst, count)), dim3(kBlock), 0, dst->stream, dst->film, staging, count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
+    (void)hipFree(staging);
+    if (e != hipSuccess) return fail(dst, PT_ERR_HIP, "pt_film_reduce: %s", hipGetErrorString(e));
     return PT_OK;
 }
 

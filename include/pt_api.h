@@ -173,6 +173,13 @@ int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcp
  * pth_tonemap16's by one step of 65535. */
 int  pt_film_tonemap16(pt_ctx *ctx, float exposure, float gamma, uint16_t *rgb_out);
 
+/* Film reduce for a process that drives several GPUs: adds the films of the other contexts to the film of
+ * ctxs[root], in index order (peer copies over xGMI + adds on the root's device), and returns when the sum is complete.
+ * All films must have the root's size; the other films are left as they are.  Contexts on the same device work too.
+ * No reference counterpart (the reference renders on one GPU).  With one process per GPU the same reduce is one
+ * RCCL call on the bound film buffers instead (see pt_film_bind). */
+int  pt_film_reduce(pt_ctx *const *ctxs, int n, int root);
+
 /* Replaces render_scene (reference src/render.cuh:50, src/render.cu:244-280): accumulates samples
  * [spp_begin, spp_begin+spp_count) of every pixel, each weighted 1/spp_total, into the bound film and returns
  * when the device is done.  Splitting [0, spp_total) over several calls, contexts or GPUs and summing the films

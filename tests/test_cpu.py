@@ -257,6 +257,14 @@ def test_tonemap_and_png(pkg, tmp_path):
     assert np.array_equal(px.astype(np.uint16), a)
 
 
+def test_command_line_usage(pkg):
+    """Wrong argument count: the usage line and exit status 0, as the reference's main does (src/main.cu:16-19)."""
+    import subprocess
+    r = subprocess.run([os.path.join(pkg.PKG_DIR, "pathtracer")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    assert r.stdout.strip() == "usage: ./pathtracer scene_file x_res y_res samples_per_pixel image_file"
+
+
 def test_scene_file_loading(pkg, tmp_path):
     """A .scene file in the reference's format: blocks, materials, and asset paths relative to the scene file."""
     tris = S.golden_mesh("bunny_lowpoly")

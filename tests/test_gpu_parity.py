@@ -211,6 +211,72 @@ def test_device_tonemap_matches_host(pkg, ctx):
     assert dev.max() > 1000 and dev.min() >= 0
 
 
+def read_pfm(path):
+    with open(path, "rb") as fh:
+        assert fh.readline().strip() == b"PF"
+        w, h = map(int, fh.readline().split())
+        assert float(fh.readline()) < 0          # little endian
+        return np.frombuffer(fh.read(), "<f4").reshape(h, w, 3)[::-1]
+
+
+def test_film_reduce_across_contexts(pkg, ctx):
+    """Two contexts render half of the samples each (as two GPUs driven by one process would); pt_film_reduce adds the
+    second film to the first: bit-equal to adding the downloaded films, and within float addition order of one call."""
+    W, H, spp = 96, 64, 8
+    scene = S.knot_scene(pkg, W, H)
+    other = pkg.Context(0)
+    try:
+        for c in (ctx, other):
+            c.upload(scene)
+            c.film_bind(W, H)
+        ctx.render(0, spp // 2, spp, seed=6)
+        other.render(spp // 2, spp - spp // 2, spp, seed=6)
+        a, b = ctx.film_download(), other.film_download()
+        pkg.film_reduce([ctx, other], root=0)
+        total = ctx.film_download()
+        assert np.array_equal(total, a + b)
+        assert np.array_equal(other.film_download(), b)
+        ctx.film_clear()
+        ctx.render(0, spp, spp, seed=6)
+        whole = ctx.film_download()
+        assert np.allclose(total, whole, rtol=1e-5, atol=1e-7)
+        with pytest.raises(pkg.PtError):
+            pkg.film_reduce([ctx, ctx])
+        other.film_bind(W + 2, H)
+        with pytest.raises(pkg.PtError):
+            pkg.film_reduce([ctx, other])
+    finally:
+        other.close()
+
+
+def test_command_line_matches_library(pkg, ctx, tmp_path):
+    """The CLI (same arguments as the reference's, src/main.cu:16-26) writes the PNG and, with PT_PFM=1, the linear
+    film: bit-equal to the film the library renders for the same scene, size, samples and seed; with the samples
+    split over two contexts (PT_DEVICES=0,0) equal up to float addition order."""
+    import subprocess
+    exe = os.path.join(pkg.PKG_DIR, "pathtracer")
+    scene_path = S.scene_file(pkg, "balls")
+    W, H, spp = 160, 90, 8
+    out = str(tmp_path / "img")
+    env = dict(os.environ, PT_PFM="1", PT_SEED="5")
+    r = subprocess.run([exe, scene_path, str(W), str(H), str(spp), out], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Rendered image in" in r.stdout and "Saved image in" in r.stdout
+    assert open(out + ".png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    cli = read_pfm(out + ".pfm")
+    hs = pkg.HostScene(scene_path, W, H)
+    ctx.upload(hs)
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=5)
+    assert np.array_equal(cli, ctx.film_download())
+    out2 = str(tmp_path / "img2")
+    r = subprocess.run([exe, scene_path, str(W), str(H), str(spp), out2], capture_output=True, text=True,
+                       env=dict(env, PT_DEVICES="0,0"), timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert '"gpus": 2' in r.stdout
+    assert np.allclose(read_pfm(out2 + ".pfm"), cli, rtol=1e-5, atol=1e-7)
+
+
 def test_render_is_partition_invariant(pkg, ctx):
     """Samples split over two calls (as two GPUs would) sum to the single-call film up to float addition order."""
     W, H, spp = 96, 64, 8
