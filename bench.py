@@ -95,7 +95,12 @@ def main():
         ctx.set_option(int(k), int(v))
         if int(k) == pkg.OPT_STREAMS:
             streams = int(v)
+    t0 = time.time()
     ctx.upload(scene)
+    t_upload = time.time() - t0
+    if rank == 0:
+        print("scene assembly %.2f s, upload %.2f s (host side, outside the timed region)" % (t_scene, t_upload),
+              file=sys.stderr)
     film = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=dev)
     ctx.film_bind(args.width, args.height, film.data_ptr())
     torch.cuda.synchronize()

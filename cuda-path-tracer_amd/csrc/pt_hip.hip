@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pt_api.h"
@@ -605,6 +606,43 @@ static bool pack_shared_exponent(float4 c, uint32_t &word)
     return word != 0;
 }
 
+// Uninitialised host storage (a std::vector would first fill gigabytes on one thread).
+template <class T>
+struct HostArray {
+    T *p;
+    explicit HostArray(size_t n) : p((T *)std::malloc(std::max<size_t>(n, 1) * sizeof(T))) {}
+    ~HostArray() { std::free(p); }
+    HostArray(const HostArray &) = delete;
+    HostArray &operator=(const HostArray &) = delete;
+    T &operator[](size_t i) { return p[i]; }
+};
+
+// host threads worth using for n independent items
+static size_t host_threads(uint64_t n)
+{
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    return (size_t)std::max<uint64_t>(1, std::min<uint64_t>(hw, n / 16384));
+}
+
+// fn(part, lo, hi) over [0, n) cut into `parts` ranges, one host thread each
+template <class F> static void parallel_chunks(uint64_t n, size_t parts, F fn)
+{
+    std::vector<std::thread> th;
+    for (size_t p = 1; p < parts; p++) th.emplace_back([=] { fn(p, n * p / parts, n * (p + 1) / parts); });
+    fn(0, 0, n / parts);
+    for (auto &t : th) t.join();
+}
+
+template <class T> static int upload_raw(pt_ctx *ctx, const T *src, size_t n, const T **dptr)
+{
+    T *d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d, std::max<size_t>(1, n) * sizeof(T)));
+    ctx->scene_allocs.push_back(d);
+    if (n) HIPCHK(ctx, hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dptr = d;
+    return PT_OK;
+}
+
 template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const T **dptr, size_t pad_elems = 0)
 {
     T *d = nullptr;
@@ -878,60 +916,79 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
         if (!s->bvh_tris || s->num_tri_float4 < 2) return fail(ctx, PT_ERR_ARG, "mesh without triangle buffer");
         const uint64_t N = s->num_nodes, M = s->num_tri_float4;
         if (N + M / 3 + 2 >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
-        std::vector<float4> recs(N * 4);
-        std::memcpy(recs.data(), s->bvh_nodes, N * 64);
-        recs.reserve((size_t)(N + s->num_tris + 1) * 4);
-        recs.push_back(make_float4(0, 0, 0, 0)); recs.push_back(make_float4(0, 0, 0, 0));
-        recs.push_back(make_float4(0, 0, 0, 0));
-        {
-            float4 meta = make_float4(0, 0, 0, 0);
-            uint32_t m[2] = {PT_PRIM_MISS, 3u};
-            std::memcpy(&meta, m, 8);
-            recs.push_back(meta);
-        }
+        // Pass 1, per leaf reference: length of its triangle run.  The reference's leaf loop stops at the first float4
+        // whose x carries the bits 0x80000000 (src/bvh.cuh:173-181), a real triangle with v00.x == -0.0f included.
         const float *tf = s->bvh_tris;
+        const int32_t *child_of = (const int32_t *)s->bvh_nodes;       // node i: words 12 and 13 of its 16
         auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-        std::vector<uint8_t> is_node_child(N, 0);
-        for (uint64_t i = 0; i < N; i++) {
-            int32_t ch[2];
-            std::memcpy(ch, &recs[i * 4 + 3], 8);
-            for (int c = 0; c < 2; c++) {
-                if (ch[c] >= 0) {
-                    if ((uint64_t)ch[c] >= N || ch[c] == 0) return fail(ctx, PT_ERR_ARG, "node %llu: child %d out of range",
-                                                                        (unsigned long long)i, ch[c]);
-                    continue;
+        std::vector<uint32_t> run(2 * N, 0);            // triangles below child c of node i at [2 i + c]
+        std::vector<int> bad(host_threads(N), 0);       // 1 child out of range, 2 run leaves the buffer, 3 truncated
+        std::vector<uint64_t> bad_node(bad.size(), 0);
+        parallel_chunks(N, bad.size(), [&](size_t part, uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi && !bad[part]; i++)
+                for (int c = 0; c < 2; c++) {
+                    const int32_t ch = child_of[i * 16 + 12 + c];
+                    int why = 0;
+                    if (ch >= 0) {
+                        if ((uint64_t)ch >= N || ch == 0) why = 1;
+                    } else {
+                        uint64_t a = (uint64_t)(uint32_t)~ch, count = 0;
+                        for (;; a += 3, count++) {
+                            if (a >= M) { why = 2; break; }
+                            if (bits(tf[a * 4]) == 0x80000000u) break;
+                            if (a + 2 >= M) { why = 3; break; }
+                        }
+                        run[2 * i + c] = (uint32_t)count;
+                    }
+                    if (why) { bad[part] = why; bad_node[part] = i; break; }
                 }
-                uint64_t a = (uint64_t)(uint32_t)~ch[c];
-                const uint64_t first = recs.size() / 4;
-                uint64_t count = 0;
-                // the reference's leaf loop stops at the first float4 whose x carries the bits 0x80000000
-                // (src/bvh.cuh:173-181), a real triangle with v00.x == -0.0f included
-                for (;; a += 3) {
-                    if (a >= M) return fail(ctx, PT_ERR_ARG, "node %llu: leaf run leaves the triangle buffer",
-                                            (unsigned long long)i);
-                    if (bits(tf[a * 4]) == 0x80000000u) break;
-                    if (a + 2 >= M) return fail(ctx, PT_ERR_ARG, "node %llu: truncated triangle", (unsigned long long)i);
-                    for (int r = 0; r < 3; r++)
-                        recs.push_back(make_float4(tf[(a + r) * 4], tf[(a + r) * 4 + 1], tf[(a + r) * 4 + 2],
-                                                   tf[(a + r) * 4 + 3]));
-                    float4 meta = make_float4(0, 0, 0, 0);
-                    uint32_t m[2] = {s->bvh_prim_ids ? s->bvh_prim_ids[a] : (uint32_t)a, 0u};
-                    std::memcpy(&meta, m, 8);
-                    recs.push_back(meta);
-                    count++;
-                }
-                if (count == 0) {
-                    ch[c] = (int32_t)N;
-                } else {
-                    uint32_t m[2];
-                    std::memcpy(m, &recs[recs.size() - 1], 8);
-                    m[1] |= 1u;
-                    std::memcpy(&recs[recs.size() - 1], m, 8);
-                    ch[c] = (int32_t)first;
-                }
-            }
-            std::memcpy(&recs[i * 4 + 3], ch, 8);
+        });
+        for (size_t part = 0; part < bad.size(); part++)
+            if (bad[part])
+                return fail(ctx, PT_ERR_ARG, "node %llu: %s", (unsigned long long)bad_node[part],
+                            bad[part] == 1 ? "child out of range"
+                                           : (bad[part] == 2 ? "leaf run leaves the triangle buffer" : "truncated triangle"));
+        // record index of every run: nodes first, then the record nothing can hit, then the runs in node order
+        std::vector<uint64_t> run_at(2 * N + 1);
+        run_at[0] = N + 1;
+        for (uint64_t k = 0; k < 2 * N; k++) run_at[k + 1] = run_at[k] + run[k];
+        const uint64_t total_recs = run_at[2 * N];
+        if (total_recs >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
+        HostArray<float4> recs(total_recs * 4);
+        if (!recs.p) return fail(ctx, PT_ERR_NOMEM, "pt_scene_upload: out of host memory");
+        {
+            float4 *nohit = recs.p + N * 4;
+            nohit[0] = nohit[1] = nohit[2] = make_float4(0, 0, 0, 0);
+            float4 meta = make_float4(0, 0, 0, 0);
+            const uint32_t m[2] = {PT_PRIM_MISS, 3u};
+            std::memcpy(&meta, m, 8);
+            nohit[3] = meta;
         }
+        // Pass 2: node records with their child references rewritten, triangle records with id and flags
+        parallel_chunks(N, bad.size(), [&](size_t, uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; i++) {
+                float4 *node = recs.p + i * 4;
+                std::memcpy(node, s->bvh_nodes + i * 16, 64);
+                int32_t ch[2];
+                std::memcpy(ch, &node[3], 8);
+                for (int c = 0; c < 2; c++) {
+                    if (ch[c] >= 0) continue;
+                    const uint64_t count = run[2 * i + c];
+                    if (count == 0) { ch[c] = (int32_t)N; continue; }
+                    uint64_t a = (uint64_t)(uint32_t)~ch[c];
+                    float4 *out = recs.p + run_at[2 * i + c] * 4;
+                    for (uint64_t k = 0; k < count; k++, a += 3, out += 4) {
+                        std::memcpy(out, tf + a * 4, 48);
+                        float4 meta = make_float4(0, 0, 0, 0);
+                        const uint32_t m[2] = {s->bvh_prim_ids ? s->bvh_prim_ids[a] : (uint32_t)a, k + 1 == count ? 1u : 0u};
+                        std::memcpy(&meta, m, 8);
+                        out[3] = meta;
+                    }
+                    ch[c] = (int32_t)run_at[2 * i + c];
+                }
+                std::memcpy(&node[3], ch, 8);
+            }
+        });
         // depth: a ray's traversal stack needs one slot per level plus the sentinel; the reference's own stack has 64
         // entries (src/bvh.cuh:12)
         uint32_t maxd = 0;
@@ -953,7 +1010,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                 return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
         }
         int rc;
-        if ((rc = upload(ctx, recs, &sc.recs)) != PT_OK) return rc;
+        if ((rc = upload_raw(ctx, recs.p, total_recs * 4, &sc.recs)) != PT_OK) return rc;
         sc.first_tri = (uint32_t)N;
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
