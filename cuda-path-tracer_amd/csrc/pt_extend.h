@@ -46,7 +46,6 @@ struct ExtendArgs {
     int refill_idle;
     int lds_slots;             // traversal stack slots per lane kept in LDS
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
-    int use_start;             // 1: ro[i].w holds the record a ray's traversal starts at (see ray_settled_at_root)
 };
 
 // Per-lane traversal state.  The hit is kept as (t, hid): hid = PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, the record index of
@@ -108,14 +107,14 @@ __device__ __forceinline__ void ray_setup(const DScene &sc, f3 o, f3 d, float &t
 }
 
 template <class STK>
-__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, const STK &stk, int start = 0)
+__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, const STK &stk)
 {
     R.o = o;
     R.d = d;
     ray_setup(sc, o, d, R.t, R.hid, R.inv, R.nood);
     stk.put(0, kSentinel);                  // bottom slot: popping it ends the traversal
     R.sp = 1;
-    R.node = sc.has_bvh ? start : kSentinel;
+    R.node = sc.has_bvh ? 0 : kSentinel;
 }
 
 // Runs the traversal's own first step on a ray that has just been created: the plane and sphere tests, then the slab
@@ -123,11 +122,8 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f
 // test for every ray.  Returns true when nothing below the root can be hit (or there is no mesh): (t, hid) then IS the
 // ray's closest hit, exactly what the extend kernel would report.  hid == PT_PRIM_MISS in that case means the ray
 // leaves the scene.  On the 868 k-triangle stand-in 53 % of all rays are settled this way, 37 % of all rays escape.
-// Otherwise `start` is where the traversal goes on: the one child that was hit (the root step pushes nothing then), or
-// the root itself when both were, for the kernel to redo that step with its stack.
-__device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d, float &t, uint32_t &hid, int &start)
+__device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d, float &t, uint32_t &hid)
 {
-    start = 0;
     Hit h;
     h.t = kFltMax; h.prim = PT_PRIM_MISS; h.n = mk3(0, 0, 0);
     for (uint32_t k = 0; k < sc.num_planes; k++) hit_plane(sc.planes[k], k, o, d, h);
@@ -140,11 +136,10 @@ __device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d
     const f3 ood = {inv.x * o.x, inv.y * o.y, inv.z * o.z};
     const f3 nood = mk3(ood.x != ood.x ? fl(0x7FC00000) : -ood.x, ood.y != ood.y ? fl(0x7FC00000) : -ood.y,
                         ood.z != ood.z ? fl(0x7FC00000) : -ood.z);
-    const float4 r0 = sc.recs[0], r1 = sc.recs[1], r2 = sc.recs[2], r3 = sc.recs[3];
+    const float4 r0 = sc.recs[0], r1 = sc.recs[1], r2 = sc.recs[2];
     float t0;
     const bool hl = hit_aabb<true>(inv, nood, r0.x, r0.y, r0.z, r0.w, r2.x, r2.y, t, t0);
     const bool hr = hit_aabb<true>(inv, nood, r1.x, r1.y, r1.z, r1.w, r2.z, r2.w, t, t0);
-    if (hl != hr) start = hl ? fi(r3.x) : fi(r3.y);
     return !(hl || hr);
 }
 
@@ -275,8 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
     RayState R;
     R.c_nodes = R.c_tris = R.c_leaves = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const float4 o4 = a.ro[i];
-        ray_begin(sc, R, xyz(o4), xyz(a.rd[i]), stk, a.use_start ? fi(o4.w) : 0);
+        ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk);
         // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
         if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true>(sc, R, stk);
         else traverse_phases<COUNT, false>(sc, R, stk);
@@ -298,11 +292,6 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
     else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
-    // Keep the record address in registers of its own until the step is over.  When the allocator lets it share
-    // registers with one of the four loaded values, the next step's address computation has to wait for every
-    // outstanding memory operation first (s_waitcnt vmcnt(0)) -- the streaming stores of rays retired at the last
-    // refill included -- which cost 18 % of the kernel's time in a build where that happened.
-    asm volatile("" ::"v"(p));
 }
 
 template <bool OVERFLOW, bool COUNT>
@@ -352,8 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
                 __builtin_amdgcn_mbcnt_hi((uint32_t)(emask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emask, 0));
             if (empty && rank < take) {
                 ray = next + rank;
-                const float4 o4 = ld_stream(a.ro + ray);
-                ray_begin(sc, R, xyz(o4), xyz(ld_stream(a.rd + ray)), stk, a.use_start ? fi(o4.w) : 0);
+                ray_begin(sc, R, xyz(ld_stream(a.ro + ray)), xyz(ld_stream(a.rd + ray)), stk);
                 degenerate = slab_degenerate(R.d);
             }
             next += take;

@@ -261,7 +261,6 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
         int cls = RAY_DROP;
         float nt = kFltMax;
         uint32_t nhid = PT_PRIM_MISS;
-        int start = 0;
         if (alive) {
             const float4 mat = material_of(sc, hid);
             const int slot = mat_slot(material_type_of(sc, hid));
@@ -280,12 +279,12 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
             // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
             // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
-            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid, start);
+            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
             cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
         const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
-            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, __int_as_float(start)));
+            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
             st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
             st_stream(B.thr + dst, th);
             if (cls == RAY_BACK) {
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
         int cls = RAY_DROP;
         float nt = kFltMax;
         uint32_t nhid = PT_PRIM_MISS;
-        int start = 0;
         f3 o = mk3(0, 0, 0), d = o;
         float4 th = make_float4(0, 0, 0, 0);
         uint32_t pixel = 0;
@@ -346,12 +344,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
             st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
             // a camera ray into the sky completes its path here; one that hits a plane or sphere in front of the mesh
             // gets its hit stored now
-            const bool settled = ray_settled_at_root(sc, o, d, nt, nhid, start);
+            const bool settled = ray_settled_at_root(sc, o, d, nt, nhid);
             cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
         }
         const uint32_t dst = block_append<kBlock>(cls, cnt, P, s_wave, s_base, par);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
-            st_stream(B.o + dst, make_float4(o.x, o.y, o.z, __int_as_float(start)));
+            st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
             st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
             st_stream(B.thr + dst, th);
             if (cls == RAY_BACK) {
@@ -689,11 +687,6 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
     a.gstk = *gstk;
-    // rays made by bounce/generate carry the record their traversal starts at; counting runs redo the root step instead
-    a.use_start = (n_on_device && !ctx->count_traversal) ? 1 : 0;
-#ifdef PT_VARIANT_NOSTART
-    a.use_start = 0;
-#endif
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
