@@ -46,8 +46,6 @@ struct ExtendArgs {
     int refill_idle;
     int lds_slots;             // traversal stack slots per lane kept in LDS
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
-    int preset_hit;            // 1: hid_out/t_out already hold every ray's closest plane / sphere hit (the kernel that made
-                               // the ray found it, see ray_settled_at_root) and the traversal starts from that
 };
 
 // Per-lane traversal state.  The hit is kept as (t, hid): hid = PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, the record index of
@@ -108,29 +106,12 @@ __device__ __forceinline__ void ray_setup(const DScene &sc, f3 o, f3 d, float &t
                ood.z != ood.z ? fl(0x7FC00000) : -ood.z);
 }
 
-// slab-test constants 1/d and -o/d (reference src/bvh.cuh:133-137), NaNs made positive
-__device__ __forceinline__ void slab_constants(f3 o, f3 d, f3 &inv, f3 &nood)
-{
-    inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const f3 ood = {inv.x * o.x, inv.y * o.y, inv.z * o.z};
-    nood = mk3(ood.x != ood.x ? fl(0x7FC00000) : -ood.x, ood.y != ood.y ? fl(0x7FC00000) : -ood.y,
-               ood.z != ood.z ? fl(0x7FC00000) : -ood.z);
-}
-
-// preset: (t, hid) is the ray's closest plane / sphere hit, found where the ray was made
 template <class STK>
-__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, const STK &stk, bool preset, float t,
-                                          uint32_t hid)
+__device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f3 d, const STK &stk)
 {
     R.o = o;
     R.d = d;
-    if (preset) {
-        R.t = t;
-        R.hid = hid;
-        slab_constants(o, d, R.inv, R.nood);
-    } else {
-        ray_setup(sc, o, d, R.t, R.hid, R.inv, R.nood);
-    }
+    ray_setup(sc, o, d, R.t, R.hid, R.inv, R.nood);
     stk.put(0, kSentinel);                  // bottom slot: popping it ends the traversal
     R.sp = 1;
     R.node = sc.has_bvh ? 0 : kSentinel;
@@ -289,9 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
     RayState R;
     R.c_nodes = R.c_tris = R.c_leaves = 0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const bool preset = a.preset_hit != 0;
-        ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk, preset, preset ? a.t_out[i] : kFltMax,
-                  preset ? a.hid_out[i] : PT_PRIM_MISS);
+        ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk);
         // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
         if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true>(sc, R, stk);
         else traverse_phases<COUNT, false>(sc, R, stk);
@@ -342,7 +321,6 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     bool degenerate = false;
     bool canon = false;          // wave-uniform: some ray in flight needs the NaN-rewriting slab test
     bool more_work = true;
-    const bool preset = a.preset_hit != 0;
 
     for (;;) {
         const int nidle = __popcll(__ballot(R.node == kSentinel));
@@ -368,18 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
                 __builtin_amdgcn_mbcnt_hi((uint32_t)(emask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emask, 0));
             if (empty && rank < take) {
                 ray = next + rank;
-                // one batch of loads: origin, direction and, for rays that bring it, the hit found where they were made
-                float4 o4 = ld_stream(a.ro + ray), d4 = ld_stream(a.rd + ray);
-                float t0 = kFltMax;
-                uint32_t h0 = PT_PRIM_MISS;
-                if (preset) {
-                    t0 = ld_stream(a.t_out + ray);
-                    h0 = ld_stream(a.hid_out + ray);
-                }
-                // all of them requested before the first is waited for (without this the unused w components are
-                // overwritten early, which puts a wait between the loads)
-                asm volatile("" : "+v"(o4.w), "+v"(d4.w), "+v"(t0), "+v"(h0));
-                ray_begin(sc, R, xyz(o4), xyz(d4), stk, preset, t0, h0);
+                ray_begin(sc, R, xyz(ld_stream(a.ro + ray)), xyz(ld_stream(a.rd + ray)), stk);
                 degenerate = slab_degenerate(R.d);
             }
             next += take;

@@ -287,9 +287,10 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
             st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
             st_stream(B.thr + dst, th);
-            // the closest plane / sphere hit: final for a ray at the back, where the traversal starts for one at the front
-            st_stream(B.hid + dst, nhid);
-            st_stream(B.t + dst, nt);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
         }
     }
 }
@@ -351,9 +352,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(DScene sc, PathBuf B, Count
             st_stream(B.o + dst, make_float4(o.x, o.y, o.z, 0.0f));
             st_stream(B.d + dst, make_float4(d.x, d.y, d.z, __uint_as_float(pixel)));
             st_stream(B.thr + dst, th);
-            // the closest plane / sphere hit: final for a ray at the back, where the traversal starts for one at the front
-            st_stream(B.hid + dst, nhid);
-            st_stream(B.t + dst, nt);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
+            }
         }
     }
 }
@@ -685,7 +687,6 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
     a.gstk = *gstk;
-    a.preset_hit = n_on_device ? 1 : 0;      // rays made by bounce / generate bring their plane / sphere hit along
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
