@@ -42,8 +42,6 @@ struct ExtendArgs {
     uint32_t n_fixed;          // ray count when n_ptr is NULL
     uint32_t *hid_out;         // hit id: PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, triangle record index, or PT_PRIM_MISS
     float *t_out;              // hit distance, FLT_MAX on a miss
-    float4 *nrm_out;           // or NULL: for triangle hits, the (unnormalised) geometric normal of the triangle, so that
-                               // the shading pass need not gather the triangle record again
     unsigned long long *cnt3;  // nodes, triangles, leaves (COUNT only)
     int refill_idle;
     int lds_slots;             // traversal stack slots per lane kept in LDS
@@ -56,7 +54,6 @@ struct RayState {
     f3 o, d, inv, nood;
     float t;
     uint32_t hid;
-    f3 n;                      // cross product of the hit triangle's two Woop rows (see hit_normal); kept only with NRM
     int node, sp;
     uint32_t c_nodes, c_tris, c_leaves;
 };
@@ -149,9 +146,7 @@ __device__ __forceinline__ bool ray_settled_at_root(const DScene &sc, f3 o, f3 d
 // Unit normal (reference src/render.cu:41) and reported primitive id of a hit, from the hit id extend stores.  The
 // triangle normal is the cross product of two Woop rows (reference src/bvh.cuh:114), the sphere normal is (p - c) / r
 // at the hit point (reference src/object.cuh:39); both are re-derived here so that traversal carries no normal around.
-// nrm: the cross product as extend stored it for this ray, or NULL to gather the triangle record.
-__device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f3 d, float t, uint32_t &prim,
-                                         const float4 *nrm = nullptr)
+__device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f3 d, float t, uint32_t &prim)
 {
     f3 n = mk3(0, 0, 0);
     prim = hid;
@@ -163,23 +158,17 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
         const f3 p = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
         n = (p - xyz(pr)) / pr.w;
     } else {
-        if (nrm) {
-            n = xyz(ld_stream(nrm));
-        } else {
-            const float4 *rec = sc.recs + (size_t)hid * 4;
-            n = cross3(xyz(rec[1]), xyz(rec[2]));
-            prim = __float_as_uint(rec[3].x);
-        }
+        const float4 *rec = sc.recs + (size_t)hid * 4;
+        n = cross3(xyz(rec[1]), xyz(rec[2]));
+        prim = __float_as_uint(rec[3].x);
     }
     return normalize3(n);
 }
 
-template <bool NRM>
-__device__ __forceinline__ void ray_retire(const RayState &R, uint32_t ray, const ExtendArgs &a)
+__device__ __forceinline__ void ray_retire(const RayState &R, uint32_t ray, uint32_t *hid_out, float *t_out)
 {
-    st_stream(a.hid_out + ray, R.hid);
-    st_stream(a.t_out + ray, R.t);
-    if (NRM && !(R.hid & (PT_PRIM_PLANE | PT_PRIM_SPHERE))) st_stream(a.nrm_out + ray, make_float4(R.n.x, R.n.y, R.n.z, 0.0f));
+    st_stream(hid_out + ray, R.hid);
+    st_stream(t_out + ray, R.t);
 }
 
 // One inner-node step (reference src/bvh.cuh:141-168): test both child boxes, descend into the nearer hit child
@@ -212,7 +201,7 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
 
 // One triangle step (reference src/bvh.cuh:171-187, 93-120): test the record, go on to the next record of the leaf or
 // pop after the last one.
-template <bool COUNT, bool NRM, class STK>
+template <bool COUNT, class STK>
 __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const STK &stk, float4 v00, float4 v11, float4 v22,
                                          float4 meta)
 {
@@ -233,7 +222,6 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
         if ((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f)) {
             R.t = t;
             R.hid = (uint32_t)R.node;
-            if (NRM) R.n = cross3(xyz(v11), xyz(v22));
         }
     }
     int next = R.node + 1;
@@ -256,7 +244,7 @@ __device__ __forceinline__ void flush_counts(const RayState &R, unsigned long lo
 }
 
 // ---- loop-per-phase traversal of one ray (reference src/bvh.cuh:139-188) -------------------------------------------
-template <bool COUNT, bool CANON, bool NRM, class STK>
+template <bool COUNT, bool CANON, class STK>
 __device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, const STK &stk)
 {
     while (R.node != kSentinel) {
@@ -266,14 +254,14 @@ __device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, c
         }
         while (R.node != kSentinel && (uint32_t)R.node >= sc.first_tri) {
             const float4 *p = sc.recs + (size_t)R.node * 4;
-            tri_step<COUNT, NRM>(sc, R, stk, p[0], p[1], p[2], p[3]);
+            tri_step<COUNT>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
     }
 }
 
 extern __shared__ int g_stack_lds[];      // [lds_slots][kBlock], sized at launch
 
-template <bool OVERFLOW, bool COUNT, bool NRM>
+template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a)
 {
     const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
@@ -281,19 +269,18 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
     const uint32_t stride = gridDim.x * kBlock;
     RayState R;
     R.c_nodes = R.c_tris = R.c_leaves = 0;
-    R.n = mk3(0, 0, 0);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         ray_begin(sc, R, xyz(a.ro[i]), xyz(a.rd[i]), stk);
         // wave-uniform choice: the NaN-rewriting slab test only when some ray of this wave needs it
-        if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true, NRM>(sc, R, stk);
-        else traverse_phases<COUNT, false, NRM>(sc, R, stk);
-        ray_retire<NRM>(R, i, a);
+        if (__any(slab_degenerate(R.d))) traverse_phases<COUNT, true>(sc, R, stk);
+        else traverse_phases<COUNT, false>(sc, R, stk);
+        ray_retire(R, i, a.hid_out, a.t_out);
     }
     flush_counts<COUNT>(R, a.cnt3);
 }
 
 // ---- persistent single-step traversal ---------------------------------------------------------------------------------
-template <bool COUNT, bool CANON, bool NRM, class STK>
+template <bool COUNT, bool CANON, class STK>
 __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
     if (R.node == kSentinel) return;
@@ -304,7 +291,7 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
-    else tri_step<COUNT, NRM>(sc, R, stk, r0, r1, r2, r3);
+    else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
     // Keep the record address in registers of its own until the step is over.  When the allocator lets it share
     // registers with one of the four loaded values, the next step's address computation has to wait for every
     // outstanding memory operation first (s_waitcnt vmcnt(0)) -- the streaming stores of rays retired at the last
@@ -312,7 +299,7 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     asm volatile("" ::"v"(p));
 }
 
-template <bool OVERFLOW, bool COUNT, bool NRM>
+template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs a)
 {
     const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
@@ -329,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     R.sp = 1;
     R.t = kFltMax;
     R.hid = PT_PRIM_MISS;
-    R.o = R.d = R.inv = R.nood = R.n = mk3(0, 0, 0);
+    R.o = R.d = R.inv = R.nood = mk3(0, 0, 0);
     uint32_t ray = kNoRay;
     bool degenerate = false;
     bool canon = false;          // wave-uniform: some ray in flight needs the NaN-rewriting slab test
@@ -340,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
         if (nidle == 64 || (more_work && nidle >= a.refill_idle)) {
             // retire finished rays, refill their slots
             if (ray != kNoRay && R.node == kSentinel) {
-                ray_retire<NRM>(R, ray, a);
+                ray_retire(R, ray, a.hid_out, a.t_out);
                 ray = kNoRay;
                 degenerate = false;
             }
@@ -371,10 +358,10 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
         // 280.1 ms per frame)
         if (canon) {
 #pragma unroll
-            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, true, NRM>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, true>(sc, R, stk);
         } else {
 #pragma unroll
-            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false, NRM>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false>(sc, R, stk);
         }
     }
     flush_counts<COUNT>(R, a.cnt3);

@@ -45,7 +45,6 @@ struct PathBuf {
     float4 *thr;    // throughput rgb, w = sample index | bounce << 27
     uint32_t *hid;  // hit id: plane / sphere / triangle record / miss  (written by extend)
     float *t;       // hit distance, FLT_MAX on a miss            (written by extend)
-    float4 *nrm;    // triangle hits: the triangle's geometric normal, unnormalised (written by extend)
 };
 
 struct Counters {
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             const int slot = mat_slot(material_type_of(sc, hid));
             const f3 o = xyz(o4), d = xyz(d4);
             uint32_t prim;
-            const f3 n3 = hit_normal(sc, hid, o, d, t, prim, A.nrm + buffer_slot(i, n_front, n, P));
+            const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
             hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
             float4 e;
@@ -562,7 +561,6 @@ static void free_pool(Lane &ln)
 {
     for (auto &b : ln.buf) {
         (void)hipFree(b.o); (void)hipFree(b.d); (void)hipFree(b.thr); (void)hipFree(b.hid); (void)hipFree(b.t);
-        (void)hipFree(b.nrm);
         b = PathBuf{};
     }
     ln.pool_alloc = 0;
@@ -580,7 +578,6 @@ static int ensure_pool(pt_ctx *ctx, Lane &ln, uint32_t slots)
         HIPCHK(ctx, hipMalloc(&b.thr, P * sizeof(float4)));
         HIPCHK(ctx, hipMalloc(&b.hid, P * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc(&b.t, P * sizeof(float)));
-        HIPCHK(ctx, hipMalloc(&b.nrm, P * sizeof(float4)));
     }
     ln.pool_alloc = slots;
     return PT_OK;
@@ -677,7 +674,7 @@ template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const
 // at 8 blocks per CU by 3 %.
 static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_on_device, int **gstk,
                          size_t *gstk_threads, const float4 *ro, const float4 *rd, uint32_t n_fixed, uint32_t n_upper,
-                         uint32_t *hid, float *t, float4 *nrm = nullptr)
+                         uint32_t *hid, float *t)
 {
     const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
     const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
@@ -698,7 +695,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.ro = ro; a.rd = rd;
     a.n_ptr = n_on_device ? &cnt->n_in : nullptr;
     a.n_fixed = n_fixed;
-    a.hid_out = hid; a.t_out = t; a.nrm_out = nrm;
+    a.hid_out = hid; a.t_out = t;
     a.cnt3 = &cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
@@ -706,8 +703,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
-#define PT_LAUNCH3(K, OV, CT, NR) hipLaunchKernelGGL((K<OV, CT, NR>), g, b, shmem, stream, ctx->sc, a)
-#define PT_LAUNCH(K, OV, CT) do { if (nrm) PT_LAUNCH3(K, OV, CT, true); else PT_LAUNCH3(K, OV, CT, false); } while (0)
+#define PT_LAUNCH(K, OV, CT) hipLaunchKernelGGL((K<OV, CT>), g, b, shmem, stream, ctx->sc, a)
     if (ctx->extend_mode == 1) {
         if (overflow) { if (count) PT_LAUNCH(k_extend_batch, true, true); else PT_LAUNCH(k_extend_batch, true, false); }
         else { if (count) PT_LAUNCH(k_extend_batch, false, true); else PT_LAUNCH(k_extend_batch, false, false); }
@@ -715,7 +711,6 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
         if (overflow) { if (count) PT_LAUNCH(k_extend_stream, true, true); else PT_LAUNCH(k_extend_stream, true, false); }
         else { if (count) PT_LAUNCH(k_extend_stream, false, true); else PT_LAUNCH(k_extend_stream, false, false); }
     }
-#undef PT_LAUNCH3
 #undef PT_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     return PT_OK;
@@ -773,7 +768,7 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
         }
         HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used], ls));
     }
-    int rc = launch_extend(ctx, ls, ln.cnt, true, &ln.gstk, &ln.gstk_threads, B.o, B.d, 0, P, B.hid, B.t, B.nrm);
+    int rc = launch_extend(ctx, ls, ln.cnt, true, &ln.gstk, &ln.gstk_threads, B.o, B.d, 0, P, B.hid, B.t);
     if (rc != PT_OK) return rc;
     if (ctx->time_extend) {
         HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used + 1], ls));
