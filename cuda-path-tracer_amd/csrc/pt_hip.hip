@@ -145,9 +145,15 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 ma
 // kBounceBlock threads claims its output range with ONE atomic, because every block adds to the same counter and
 // same-address atomics are what this kernel would otherwise wait for.
 // --------------------------------------------------------------------------------------------------------------
-// threads per block = rays per output claim.  Measured ms per frame (dragon stand-in / spheres only) for 256, 512, 1024:
-// 342 / 335 / 341 and 124 / 117 / 121.
-constexpr int kBounceBlock = 512;
+// threads per block = rays per output claim.  The threads of a block move in lock step (two barriers per batch), so a
+// smaller block lets more of the gathers of different batches overlap; a larger one needs fewer of the same-address
+// atomics, which all blocks of all kernels of a stream share.  Measured ms per frame (868 k-triangle stand-in / spheres
+// only) with generate at 512: bounce 64 -> 345 / 130, 128 -> 271 / 87, 256 -> 251 / 72.6, 512 -> 260 / 75.8,
+// 1024 -> 265 / 80; with bounce at 256, generate 256 -> 249 / 77.4.
+#ifndef PT_BOUNCEBLOCK
+#define PT_BOUNCEBLOCK 256
+#endif
+constexpr int kBounceBlock = PT_BOUNCEBLOCK;
 
 // slot of the i-th ray of a buffer whose front holds n_front rays and whose back holds the rest
 __device__ __forceinline__ uint32_t buffer_slot(uint32_t i, uint32_t n_front, uint32_t n_total, uint32_t P)
