@@ -313,13 +313,12 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
 // generate: reference src/render.cu:93-127
 // --------------------------------------------------------------------------------------------------------------
 // one thread, before generate: how many camera paths this iteration starts (as many as the buffer has room for)
-__global__ void k_take(Counters *cnt, uint32_t P, uint32_t cap)
+__global__ void k_take(Counters *cnt, uint32_t P)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const unsigned long long remaining = cnt->total_samples - cnt->next_sample;
     const unsigned long long room = P - (uint32_t)cnt->n_out - (uint32_t)(cnt->n_out >> 32);
-    uint32_t take = (uint32_t)(remaining < room ? remaining : room);
-    take = take < cap ? take : cap;
+    const uint32_t take = (uint32_t)(remaining < room ? remaining : room);
     cnt->take = take;
     cnt->gen_first = cnt->next_sample;
     cnt->next_sample += take;
@@ -487,7 +486,6 @@ struct Lane {
     // state of the slab share being rendered
     uint64_t first = 0, count = 0, total = 0, min_iters = 0, it = 0;
     uint32_t P = 0;
-    uint32_t first_take = 0;       // camera paths the first iteration may start (staggers the lanes)
     float4 *slab = nullptr;
     size_t ev_used = 0;
     int cur = 0;
@@ -725,7 +723,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
 }
 
 // Points a lane at its share of a slab: `count` samples from `first`, slab entries at `slab`.
-static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, float4 *slab, int nlanes, int index)
+static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, float4 *slab, int nlanes)
 {
     const uint64_t npix = (uint64_t)ctx->W * ctx->H;
     ln.first = first;
@@ -738,7 +736,6 @@ static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, flo
     int rc = ensure_pool(ctx, ln, ln.P);
     if (rc != PT_OK) return rc;
     ln.min_iters = (ln.total + ln.P - 1) / ln.P;
-    ln.first_take = (uint32_t)std::max<uint64_t>(1024, (uint64_t)ln.P * (index + 1) / nlanes);
     ln.it = 0;
     ln.cur = 0;
     ln.ev_used = 0;
@@ -763,9 +760,7 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     if (ln.it > 0)
         hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
                            (uint32_t)ln.first, npix, s0, s1);
-    // the first iteration of lane k of n starts (k + 1) / n of a full buffer, which puts the lanes out of step: their
-    // extend launches then follow one another instead of all running, and all pausing, at the same time
-    hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P, ln.it == 0 ? ln.first_take : P);
+    hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
     const int gg = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kGenBlock),
                                                                  ((uint64_t)P + kGenBlock - 1) / kGenBlock));
     hipLaunchKernelGGL(k_generate, dim3(gg), dim3(kGenBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first, s0, s1,
@@ -1378,7 +1373,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
         for (int k = 0; k < nl; k++) {
             const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
-            int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl, k);
+            int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
             if (rc != PT_OK) return rc;
         }
         // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
