@@ -384,7 +384,10 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
 // where it was made (it escaped, or it hit a plane or sphere in front of the mesh) still is a closest-hit query that
 // was answered -- by the first step of the traversal -- so it counts as a ray, and as one node visit when the scene has
 // a tree.
-__global__ void k_advance(Counters *cnt, uint32_t count_root_visits)
+// `done` points into pinned host memory: set once the buffer is empty and no samples are left, which is all the host
+// needs to know while a render runs (a copy of the counters per iteration would put a blit kernel on the stream, 0.2 to
+// 1 ms each beside the other streams' kernels).
+__global__ void k_advance(Counters *cnt, uint32_t count_root_visits, uint32_t *done)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const uint32_t n_front = (uint32_t)cnt->n_out, n_back = (uint32_t)(cnt->n_out >> 32);
@@ -398,6 +401,8 @@ __global__ void k_advance(Counters *cnt, uint32_t count_root_visits)
     if (n_front) cnt->extend_nonempty += 1;
     cnt->n_out = 0;
     cnt->n_escaped = 0;
+    if (n_front == 0 && n_back == 0 && cnt->next_sample >= cnt->total_samples)
+        __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Divides a pixel's slab entries by the sample count, sums them in sample order and adds the sum to the film (float3
@@ -477,7 +482,9 @@ struct Lane {
     uint32_t pool_alloc = 0;
     PathBuf buf[2]{};
     Counters *cnt = nullptr;
-    Counters *h_cnt = nullptr;     // pinned: 4 polling slots + 1 initial value
+    Counters *h_cnt = nullptr;     // pinned: final counters [0], initial value [4]
+    uint32_t *h_done = nullptr;    // pinned, written by k_advance: 1 when the lane has run out of work
+    uint32_t *d_done = nullptr;    // the same word as the device addresses it
     int *gstk = nullptr;           // traversal stack overflow of this lane's extend launches
     size_t gstk_threads = 0;
     std::vector<hipEvent_t> events;
@@ -740,6 +747,7 @@ static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, flo
     ln.cur = 0;
     ln.ev_used = 0;
     ln.done = false;
+    __atomic_store_n(ln.h_done, 0u, __ATOMIC_RELEASE);
     Counters &init = ln.h_cnt[4];
     init = Counters{};
     init.total_samples = ln.total;
@@ -765,7 +773,8 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
                                                                  ((uint64_t)P + kGenBlock - 1) / kGenBlock));
     hipLaunchKernelGGL(k_generate, dim3(gg), dim3(kGenBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first, s0, s1,
                        ln.slab);
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u,
+                       ln.d_done);
     if (ctx->time_extend) {
         while (ln.events.size() < ln.ev_used + 2) {
             hipEvent_t ev;
@@ -784,13 +793,12 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     ln.it++;
     if (ln.it >= ln.min_iters) {
         const int slot = (int)(ln.it & 3);
-        HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[slot], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ls));
         HIPCHK(ctx, hipEventRecord(ln.poll_ev[slot], ls));
         if (ln.it >= ln.min_iters + 2) {
+            // wait for the iteration two behind the launch front, then look at the word k_advance writes
             const int old = (int)((ln.it - 2) & 3);
             HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
-            const Counters &c = ln.h_cnt[old];
-            if (c.n_in == 0 && c.n_back_in == 0 && c.next_sample >= c.total_samples) ln.done = true;
+            if (__atomic_load_n(ln.h_done, __ATOMIC_ACQUIRE) != 0) ln.done = true;
         }
     }
     return PT_OK;
@@ -829,6 +837,8 @@ int pt_ctx_create(int device, pt_ctx **out)
         CREATECHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         CREATECHK(hipMalloc(&ln.cnt, sizeof(Counters)));
         CREATECHK(hipHostMalloc(&ln.h_cnt, 5 * sizeof(Counters)));
+        CREATECHK(hipHostMalloc(&ln.h_done, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        CREATECHK(hipHostGetDevicePointer((void **)&ln.d_done, ln.h_done, 0));
         for (auto &ev : ln.poll_ev) CREATECHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         CREATECHK(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
     }
@@ -851,6 +861,7 @@ void pt_ctx_destroy(pt_ctx *ctx)
         (void)hipFree(ln.cnt);
         (void)hipFree(ln.gstk);
         if (ln.h_cnt) (void)hipHostFree(ln.h_cnt);
+        if (ln.h_done) (void)hipHostFree(ln.h_done);
         for (auto ev : ln.events) (void)hipEventDestroy(ev);
         for (auto ev : ln.poll_ev) if (ev) (void)hipEventDestroy(ev);
         if (ln.ev_done) (void)hipEventDestroy(ln.ev_done);
