@@ -96,33 +96,34 @@ __device__ __forceinline__ float4 escape_value(float4 th, float4 e)
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// shade: reference src/render.cu:129-242.  One material per instantiation; returns the new direction and scales the
-// throughput.  env_out = environment texel in the new direction (the Lambertian pdf needs it, the caller stores the
-// path's escape value from it).
+// shade: reference src/render.cu:129-242.  Returns the new direction and scales the throughput.  env_out = environment
+// texel in the new direction (the Lambertian pdf needs it, the caller stores the path's escape value from it).
+// One body for all four materials, chosen per lane by `slot` (0 Lambertian, 1 glossy, 2 mirror, 3 glass): the lanes of a
+// wave hit different materials, and with a body per material the wave ran the Lambertian sampling and the environment
+// lookup once for each material present.  Each lane still draws its random numbers in the order its material's
+// reference kernel does.
 // --------------------------------------------------------------------------------------------------------------
-template <int MAT>
-__device__ __forceinline__ f3 shade_dir(const DScene &sc, f3 d, f3 n3, float4 mat, Rng &rng, float4 &th, float4 &env_out)
+__device__ __forceinline__ f3 shade_dir(const DScene &sc, int slot, f3 d, f3 n3, float4 mat, Rng &rng, float4 &th,
+                                        float4 &env_out)
 {
-    f3 out;
-    bool lambert = false;
-    if (MAT == 2) {                                     // mirror (src/render.cu:195-211)
-        out = reflect3(d, n3);
-        th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
-    } else if (MAT == 3) {                              // glass (src/render.cu:213-242)
+    f3 out = mk3(0, 0, 0);
+    bool lambert = slot == 0;                           // Lambertian (src/render.cu:129-162)
+    bool mirror = slot == 2;                            // mirror (src/render.cu:195-211)
+    f3 nn = n3;                                         // the normal a reflection uses
+    if (slot == 3) {                                    // glass (src/render.cu:213-242)
         const bool external = dot3(d, n3) < 0;
-        const f3 nn = external ? n3 : -n3;
+        nn = external ? n3 : -n3;
         const float ref_idx = external ? (1 / mat.w) : mat.w;
         const float cos_t = fminf(dot3(-d, nn), 1.0f);
         const float sin_t = sqrtf(__fmaf_rn(-cos_t, cos_t, 1.0f));
-        if (ref_idx * sin_t > 1.0f || schlick(cos_t, ref_idx) > rng.next()) out = reflect3(d, nn);
+        if (ref_idx * sin_t > 1.0f || schlick(cos_t, ref_idx) > rng.next()) mirror = true;
         else out = refract_dir(d, nn, ref_idx);
-        th.x *= mat.x; th.y *= mat.y; th.z *= mat.z;
-    } else if (MAT == 1) {                              // glossy (src/render.cu:164-193)
-        if (rng.next() < 0.05f) out = reflect3(d, n3);  // throughput untouched
+    } else if (slot == 1) {                             // glossy (src/render.cu:164-193)
+        if (rng.next() < 0.05f) mirror = true;          // throughput untouched
         else lambert = true;
-    } else {
-        lambert = true;                                 // Lambertian (src/render.cu:129-162)
     }
+    if (mirror) out = reflect3(d, nn);
+    if (slot >= 2) { th.x *= mat.x; th.y *= mat.y; th.z *= mat.z; }
     if (lambert) out = (rng.next() < 0.5f) ? diffuse_dir(n3, rng) : env_sample_lights(sc, rng);
     env_out = env_lookup(sc, out);
     if (lambert) {
@@ -283,10 +284,7 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
             hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
             float4 e;
-            if (slot == 0) out = shade_dir<0>(sc, d, n3, mat, rng, th, e);
-            else if (slot == 1) out = shade_dir<1>(sc, d, n3, mat, rng, th, e);
-            else if (slot == 2) out = shade_dir<2>(sc, d, n3, mat, rng, th, e);
-            else out = shade_dir<3>(sc, d, n3, mat, rng, th, e);
+            out = shade_dir(sc, slot, d, n3, mat, rng, th, e);
             st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
             th.w = __uint_as_float(sample | ((k + 1) << 27));
             // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
