@@ -179,12 +179,12 @@ template <bool CANON>
 __device__ __forceinline__ bool hit_aabb(f3 inv, f3 nood, float x0, float x1, float y0, float y1, float z0, float z1,
                                          float t_max, float &t0)
 {
-    // both planes of an axis in one packed fma (v_pk_fma_f32): the same fused operations, half the instructions
-    typedef float pair __attribute__((ext_vector_type(2)));
-    const pair px = __builtin_elementwise_fma(pair{x0, x1}, pair{inv.x, inv.x}, pair{nood.x, nood.x});
-    const pair py = __builtin_elementwise_fma(pair{y0, y1}, pair{inv.y, inv.y}, pair{nood.y, nood.y});
-    const pair pz = __builtin_elementwise_fma(pair{z0, z1}, pair{inv.z, inv.z}, pair{nood.z, nood.z});
-    float lox = px.x, hix = px.y, loy = py.x, hiy = py.y, loz = pz.x, hiz = pz.y;
+    float lox = __fmaf_rn(x0, inv.x, nood.x);
+    float hix = __fmaf_rn(x1, inv.x, nood.x);
+    float loy = __fmaf_rn(y0, inv.y, nood.y);
+    float hiy = __fmaf_rn(y1, inv.y, nood.y);
+    float loz = __fmaf_rn(z0, inv.z, nood.z);
+    float hiz = __fmaf_rn(z1, inv.z, nood.z);
     if (CANON) {
         lox = pos_nan(lox); hix = pos_nan(hix); loy = pos_nan(loy); hiy = pos_nan(hiy); loz = pos_nan(loz); hiz = pos_nan(hiz);
     }
