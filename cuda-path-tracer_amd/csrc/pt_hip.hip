@@ -228,112 +228,6 @@ __device__ __forceinline__ void flush_escaped(Counters *cnt, uint32_t escaped)
     if ((threadIdx.x & 63u) == 0 && escaped) atomicAdd(&cnt->n_escaped, escaped);
 }
 
-// block_append for R rays per thread: one claim covers all R batches of the block
-template <int BLOCK, int R>
-__device__ __forceinline__ void block_append_n(const int (&cls)[R], Counters *cnt, uint32_t P,
-                                               uint32_t (&s_wave)[2][BLOCK / 64], unsigned long long (&s_base)[2], int par,
-                                               uint32_t &escaped, uint32_t (&dst)[R])
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long fmask[R], bmask[R];
-    uint32_t nf = 0, nb = 0;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        fmask[r] = __ballot(cls[r] == RAY_FRONT);
-        bmask[r] = __ballot(cls[r] == RAY_BACK);
-        escaped += (uint32_t)__popcll(__ballot(cls[r] == RAY_ESCAPED));
-        nf += (uint32_t)__popcll(fmask[r]);
-        nb += (uint32_t)__popcll(bmask[r]);
-    }
-    if (lane == 0) s_wave[par][wave] = nf | (nb << 16);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; w++) {
-        const uint32_t c = s_wave[par][w];
-        before += (uint32_t)w < wave ? c : 0u;
-        total += c;
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long add = (unsigned long long)(total & 0xFFFFu) | ((unsigned long long)(total >> 16) << 32);
-        s_base[par] = add ? atomicAdd(&cnt->n_out, add) : 0ull;
-    }
-    __syncthreads();
-    const unsigned long long base = s_base[par];
-    uint32_t f = (uint32_t)base + (before & 0xFFFFu), bk = (uint32_t)(base >> 32) + (before >> 16);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        const uint32_t rf = __builtin_amdgcn_mbcnt_hi((uint32_t)(fmask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fmask[r], 0));
-        const uint32_t rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask[r], 0));
-        dst[r] = cls[r] == RAY_FRONT ? f + rf : P - 1u - (bk + rb);
-        f += (uint32_t)__popcll(fmask[r]);
-        bk += (uint32_t)__popcll(bmask[r]);
-    }
-}
-
-struct BounceOut { float4 o, d, th; float nt; uint32_t nhid; int cls; };
-
-// logic + shade of one ray (see above); the ray that continues the path comes back unplaced
-__device__ __forceinline__ BounceOut bounce_one(const DScene &sc, const BounceIn &in, float4 *__restrict__ slab,
-                                                uint32_t slab_first_sample, uint32_t npix, uint32_t seed0, uint32_t seed1)
-{
-    bool alive = false;
-    float4 th = in.th;
-    const float4 d4 = in.d4, o4 = in.o4;
-    const float t = in.t;
-    const uint32_t hid = in.hid;
-    const uint32_t sk = __float_as_uint(th.w);
-    const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-    const uint32_t pixel = __float_as_uint(d4.w);
-    // a miss or the depth limit ends the path with the escape value its slab entry already holds
-    if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
-        alive = true;
-        if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
-            Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
-            const float p = fmaxf(th.x, fmaxf(th.y, th.z));
-            if (rng.next() > p) {
-                alive = false;
-                st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-            } else {
-                const float ip = 1 / p;
-                th.x *= ip; th.y *= ip; th.z *= ip;
-            }
-        }
-    }
-    BounceOut r;
-    r.o = r.d = r.th = make_float4(0, 0, 0, 0);
-    r.cls = RAY_DROP;
-    r.nt = kFltMax;
-    r.nhid = PT_PRIM_MISS;
-    if (alive) {
-        const float4 mat = material_of(sc, hid);
-        const int slot = mat_slot(material_type_of(sc, hid));
-        const f3 o = xyz(o4), d = xyz(d4);
-        uint32_t prim;
-        const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
-        const f3 hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
-        Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
-        float4 e;
-        const f3 out = shade_dir(sc, slot, d, n3, mat, rng, th, e);
-        st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
-        th.w = __uint_as_float(sample | ((k + 1) << 27));
-        // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
-        // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
-        // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
-        const bool settled = ray_settled_at_root(sc, hitp, out, r.nt, r.nhid);
-        r.cls = !settled ? RAY_FRONT : (r.nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
-        r.o = make_float4(hitp.x, hitp.y, hitp.z, 0.0f);
-        r.d = make_float4(out.x, out.y, out.z, d4.w);
-        r.th = th;
-    }
-    return r;
-}
-
-#ifndef PT_BOUNCE_RAYS
-#define PT_BOUNCE_RAYS 1
-#endif
-constexpr int kBounceRays = PT_BOUNCE_RAYS;      // rays per thread and claim
-
 __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, PathBuf B, Counters *cnt,
                                                          uint32_t P, float4 *__restrict__ slab,
                                                          uint32_t slab_first_sample, uint32_t npix, uint32_t seed0,
@@ -341,46 +235,72 @@ __global__ __launch_bounds__(kBounceBlock) void k_bounce(DScene sc, PathBuf A, P
 {
     __shared__ uint32_t s_wave[2][kBounceBlock / 64];
     __shared__ unsigned long long s_base[2];
-    constexpr uint32_t kPerIter = kBounceBlock * kBounceRays;
     uint32_t escaped = 0;
     const uint32_t n_front = cnt->n_in;
     const uint32_t n = n_front + cnt->n_back_in;
-    const uint64_t stride = (uint64_t)gridDim.x * kPerIter;
+    const uint32_t stride = gridDim.x * kBounceBlock;
     int par = 0;
-    BounceIn nxt[kBounceRays];
-#pragma unroll
-    for (int r = 0; r < kBounceRays; r++)
-        nxt[r] = bounce_load(A, blockIdx.x * kPerIter + r * kBounceBlock + threadIdx.x, n, n_front, P);
+    BounceIn nxt = bounce_load(A, blockIdx.x * kBounceBlock + threadIdx.x, n, n_front, P);
     // the trip count is the same for every thread of a block (barriers inside)
-    for (uint64_t first = (uint64_t)blockIdx.x * kPerIter; first < n; first += stride, par ^= 1) {
-        // the state of the block's next rays is requested before this batch is shaded, so that the streaming loads of
-        // one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
-        BounceIn in[kBounceRays];
-        BounceOut out[kBounceRays];
-        int cls[kBounceRays];
-        uint32_t dst[kBounceRays];
-#pragma unroll
-        for (int r = 0; r < kBounceRays; r++) {
-            in[r] = nxt[r];
-            const uint64_t j = first + stride + r * kBounceBlock + threadIdx.x;
-            nxt[r] = bounce_load(A, (uint32_t)(j < n ? j : 0), j < n ? n : 0u, n_front, P);
-        }
-#pragma unroll
-        for (int r = 0; r < kBounceRays; r++) {
-            out[r] = bounce_one(sc, in[r], slab, slab_first_sample, npix, seed0, seed1);
-            cls[r] = out[r].cls;
-        }
-        block_append_n<kBounceBlock, kBounceRays>(cls, cnt, P, s_wave, s_base, par, escaped, dst);
-#pragma unroll
-        for (int r = 0; r < kBounceRays; r++) {
-            if (cls[r] == RAY_FRONT || cls[r] == RAY_BACK) {
-                st_stream(B.o + dst[r], out[r].o);
-                st_stream(B.d + dst[r], out[r].d);
-                st_stream(B.thr + dst[r], out[r].th);
-                if (cls[r] == RAY_BACK) {
-                    st_stream(B.hid + dst[r], out[r].nhid);
-                    st_stream(B.t + dst[r], out[r].nt);
+    for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
+        const uint32_t i = first + threadIdx.x;
+        // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming loads
+        // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
+        const BounceIn in = nxt;
+        nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u, n_front, P);
+        bool alive = false;
+        float4 th = in.th;
+        const float4 d4 = in.d4, o4 = in.o4;
+        const float t = in.t;
+        const uint32_t hid = in.hid;
+        const uint32_t sk = __float_as_uint(th.w);
+        const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+        const uint32_t pixel = __float_as_uint(d4.w);
+        // a miss or the depth limit ends the path with the escape value its slab entry already holds
+        if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
+            alive = true;
+            if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+                Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+                const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+                if (rng.next() > p) {
+                    alive = false;
+                    st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                } else {
+                    const float ip = 1 / p;
+                    th.x *= ip; th.y *= ip; th.z *= ip;
                 }
+            }
+        }
+        f3 out = mk3(0, 0, 0), hitp = out;
+        int cls = RAY_DROP;
+        float nt = kFltMax;
+        uint32_t nhid = PT_PRIM_MISS;
+        if (alive) {
+            const float4 mat = material_of(sc, hid);
+            const int slot = mat_slot(material_type_of(sc, hid));
+            const f3 o = xyz(o4), d = xyz(d4);
+            uint32_t prim;
+            const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
+            hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
+            Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
+            float4 e;
+            out = shade_dir(sc, slot, d, n3, mat, rng, th, e);
+            st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
+            th.w = __uint_as_float(sample | ((k + 1) << 27));
+            // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
+            // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
+            // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
+            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
+            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+        }
+        const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par, escaped);
+        if (cls == RAY_FRONT || cls == RAY_BACK) {
+            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
+            st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
+            st_stream(B.thr + dst, th);
+            if (cls == RAY_BACK) {
+                st_stream(B.hid + dst, nhid);
+                st_stream(B.t + dst, nt);
             }
         }
     }
@@ -842,8 +762,7 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     hipStream_t ls = ln.stream;
     PathBuf A = ln.buf[ln.cur], B = ln.buf[ln.cur ^ 1];
     const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
-                                                                 ((uint64_t)P + kBounceBlock * kBounceRays - 1) /
-                                                                     (kBounceBlock * kBounceRays)));
+                                                                 ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
     if (ln.it > 0)
         hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
                            (uint32_t)ln.first, npix, s0, s1);
