@@ -473,6 +473,53 @@ def test_error_paths(pkg):
     c.close()
 
 
+def test_upload_rejects_malformed_bvh_buffers(pkg):
+    """pt_scene_upload validates what it re-lays (in parallel passes for large meshes): a child index outside the node
+    array, a leaf reference past the triangle buffer, a leaf run without terminator and a cycle are refused with an
+    error instead of producing a tree the traversal could run off."""
+    tris = S.knot_mesh(pkg)
+    rng = np.random.default_rng(3)
+    big = np.concatenate([tris + rng.uniform(-2, 2, size=(1, 1, 3)).astype(np.float32) for _ in range(4)])
+    good = pkg.bvh_build(big, threads=4)                  # 36,864 triangles: enough nodes for several upload threads
+    cam = pkg.camera_make((0, 1, 6), (0, 0, 0), 40.0, 1.5, 0.0, 6.0)
+    tex, marg, cond = S.small_env(pkg)
+    c = pkg.Context(0)
+
+    def upload(bvh):
+        c.upload(pkg.ManualScene(cam, tex, marg, cond, bvh=bvh))
+
+    upload(good)                                          # the untouched buffers are fine
+    n_nodes = good["nodes"].shape[0]
+
+    def broken(edit):
+        b = dict(good)
+        b["nodes"] = good["nodes"].copy()
+        b["tris"] = good["tris"].copy()
+        edit(b)
+        return b
+
+    def child_out_of_range(b):
+        b["nodes"].view(np.int32)[n_nodes // 2, 12] = n_nodes + 5
+
+    def leaf_past_the_buffer(b):
+        b["nodes"].view(np.int32)[n_nodes - 1, 13] = ~np.int32(good["num_tri_float4"] + 7)
+
+    def run_without_terminator(b):
+        t = b["tris"].view(np.uint32)
+        t[t[:, 0] == 0x80000000, 0] = 0x3F800000          # no float4 ends a run any more
+
+    def cycle(b):
+        b["nodes"].view(np.int32)[n_nodes - 1, 12] = 1    # a deep node points back up: not a tree
+
+    for edit in (child_out_of_range, leaf_past_the_buffer, run_without_terminator, cycle):
+        with pytest.raises(pkg.PtError):
+            upload(broken(edit))
+    upload(good)                                          # and the context still works afterwards
+    t, prim = c.intersect(np.array([[0, 1, 6]], np.float32), np.array([[0, -0.16, -1]], np.float32))[:2]
+    assert t.shape == (1,)
+    c.close()
+
+
 def test_full_size_frame_properties(pkg, ctx):
     """At the benchmark's resolution (1920x1080) the oracle is too slow to run in full, so check size-independent
     properties: every path is started exactly once, splitting the samples does not change the film, the film is
