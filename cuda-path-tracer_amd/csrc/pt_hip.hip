@@ -475,8 +475,6 @@ __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint3
 // generate by streaming state through HBM, so one lane's extend runs beside another lane's bounce.  Measured on the
 // headline frame, 1 / 2 / 3 / 4 lanes: 324 / 280 / 269 / 288 ms.
 constexpr int kMaxLanes = 4;
-constexpr int kPollRing = 8;       // events per lane
-constexpr uint64_t kRunAhead = 6;  // iterations a lane may have queued beyond the last one known to be complete
 struct Lane {
     hipStream_t stream = nullptr;
     uint32_t pool_alloc = 0;
@@ -488,11 +486,10 @@ struct Lane {
     int *gstk = nullptr;           // traversal stack overflow of this lane's extend launches
     size_t gstk_threads = 0;
     std::vector<hipEvent_t> events;
-    hipEvent_t poll_ev[kPollRing]{};   // recorded after every iteration; bounds how far the host runs ahead
+    hipEvent_t poll_ev[4]{};
     hipEvent_t ev_done = nullptr;
     // state of the slab share being rendered
-    uint64_t first = 0, count = 0, total = 0, it = 0;
-    uint64_t completed = 0;        // iterations whose poll event has been seen complete
+    uint64_t first = 0, count = 0, total = 0, min_iters = 0, it = 0;
     uint32_t P = 0;
     float4 *slab = nullptr;
     size_t ev_used = 0;
@@ -743,8 +740,8 @@ static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, flo
     ln.P = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(1024u, ctx->pool / (uint32_t)nlanes), want);
     int rc = ensure_pool(ctx, ln, ln.P);
     if (rc != PT_OK) return rc;
+    ln.min_iters = (ln.total + ln.P - 1) / ln.P;
     ln.it = 0;
-    ln.completed = 0;
     ln.cur = 0;
     ln.ev_used = 0;
     ln.done = false;
@@ -757,7 +754,8 @@ static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, flo
     return PT_OK;
 }
 
-// Queues one wavefront iteration of a lane (bounce, take, generate, advance, extend) and an event behind it.
+// Queues one wavefront iteration of a lane (bounce, take, generate, advance, extend) and, once the lane can have run
+// out of work, polls its device counters two iterations behind the launch front; sets ln.done when they say so.
 static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
 {
     const uint32_t W = ctx->W, H = ctx->H, npix = W * H, P = ln.P;
@@ -789,9 +787,18 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
         HIPCHK(ctx, hipEventRecord(ln.events[ln.ev_used + 1], ls));
         ln.ev_used += 2;
     }
-    HIPCHK(ctx, hipEventRecord(ln.poll_ev[ln.it % kPollRing], ls));
     ln.cur ^= 1;
     ln.it++;
+    if (ln.it >= ln.min_iters) {
+        const int slot = (int)(ln.it & 3);
+        HIPCHK(ctx, hipEventRecord(ln.poll_ev[slot], ls));
+        if (ln.it >= ln.min_iters + 2) {
+            // wait for the iteration two behind the launch front, then look at the word k_advance writes
+            const int old = (int)((ln.it - 2) & 3);
+            HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[old]));
+            if (__atomic_load_n(ln.h_done, __ATOMIC_ACQUIRE) != 0) ln.done = true;
+        }
+    }
     return PT_OK;
 }
 
@@ -1378,36 +1385,14 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
             int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
             if (rc != PT_OK) return rc;
         }
-        // Round robin: one iteration per live lane, so that the lanes' kernels are queued side by side.  A lane is done
-        // when k_advance has set its word in pinned memory (it stays set); each lane keeps up to kRunAhead iterations
-        // queued, and the host never waits for one lane while another has room -- towards the end of a slab a lane's
-        // iterations take microseconds, and a host blocked on a lane that is still in its long ones starved the rest
-        // (gaps of 3 to 5 ms in the kernel trace).
+        // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
         for (int live = nl; live > 0;) {
-            bool queued = false;
             for (int k = 0; k < nl; k++) {
                 Lane &ln = ctx->lanes[k];
                 if (ln.done) continue;
-                while (ln.completed < ln.it && hipEventQuery(ln.poll_ev[ln.completed % kPollRing]) == hipSuccess) ln.completed++;
-                if (__atomic_load_n(ln.h_done, __ATOMIC_ACQUIRE) != 0) {
-                    ln.done = true;
-                    live--;
-                    continue;
-                }
-                if (ln.it - ln.completed < kRunAhead) {
-                    int rc = lane_iterate(ctx, ln, s0, s1);
-                    if (rc != PT_OK) return rc;
-                    queued = true;
-                }
-            }
-            if (!queued && live > 0) {
-                // every live lane has its run-ahead queued: wait for the oldest iteration of the first of them
-                for (int k = 0; k < nl; k++) {
-                    Lane &ln = ctx->lanes[k];
-                    if (ln.done) continue;
-                    HIPCHK(ctx, hipEventSynchronize(ln.poll_ev[ln.completed % kPollRing]));
-                    break;
-                }
+                int rc = lane_iterate(ctx, ln, s0, s1);
+                if (rc != PT_OK) return rc;
+                if (ln.done) live--;
             }
         }
         // every path of this slab has ended and its entry holds what it contributes: fold the slab into the film
