@@ -292,8 +292,12 @@ __device__ __forceinline__ f3 env_sample_lights(const DScene &sc, Rng &rng)
     uint32_t y = sc.cond[(size_t)x * H + i2];
     float phi = 2.0f * (float)x * kPi / (float)W;
     float theta = (float)y * kPi / (float)H;
-    float sin_t = -sinf(theta);
-    return {sin_t * cosf(phi), -cosf(theta), sin_t * sinf(phi)};
+    // sincosf shares the argument reduction and returns what sinf and cosf return
+    float st, ct, sp, cp;
+    sincosf(theta, &st, &ct);
+    sincosf(phi, &sp, &cp);
+    float sin_t = -st;
+    return {sin_t * cp, -ct, sin_t * sp};
 }
 
 // ---- materials --------------------------------------------------------------------------------------------------
@@ -303,8 +307,10 @@ __device__ __forceinline__ f3 diffuse_dir(f3 n, Rng &rng)
     float z = __fmaf_rn(rng.next(), 2.0f, -1.0f);
     float a = rng.next() * 2.0f * kPi;
     float r = sqrtf(__fmaf_rn(-z, z, 1.0f));
-    float x = r * cosf(a);
-    float y = r * sinf(a);
+    float sa, ca;
+    sincosf(a, &sa, &ca);
+    float x = r * ca;
+    float y = r * sa;
     f3 dir = mk3(x, y, z) + n;
     if (dir.x < kEps && dir.y < kEps && dir.z < kEps) return n;
     return normalize3(dir);
