@@ -15,7 +15,7 @@ The JSON line also carries
                 means counted by the CPU oracle on a reduced-resolution run of the same scene) times the rays of the
                 timed steps, divided by the HIP-event time of the extend launches on the library's own stream;
   cpu_baseline  the CPU oracle (a host restatement of the reference's traversal and shading) timed on this machine's
-                cores on a bounded sample of the same workload (960x540, 48 spp).
+                cores on a bounded sample of the same workload (960x540, 320 spp).
 """
 import argparse
 import json
@@ -177,7 +177,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             import oracle_lib as O
 
-            cw, ch, cspp = 960, 540, 48
+            cw, ch, cspp = 960, 540, 320      # about 10 s on 16 cores
             cscene = make_scene(cw, ch)
             threads = min(os.cpu_count() or 1, 16)
             _, ost = O.render(S.as_oracle_desc(cscene), cw, ch, 0, cspp, cspp, seed=1, nthreads=threads)
