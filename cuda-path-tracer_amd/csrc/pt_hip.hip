@@ -24,7 +24,6 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1382,19 +1381,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         // entry, so the film does not depend on the lane count.
         const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
         for (int k = 0; k < nl; k++) {
-            // share of lane k: weights 1 + skew, ..., 1 - skew (PT_SKEW, per cent; experiment)
-            auto cut = [&](int j) -> uint64_t {
-                static const int skew = std::getenv("PT_SKEW") ? std::atoi(std::getenv("PT_SKEW")) : 0;
-                if (nl < 2 || skew == 0) return count * j / nl;
-                double acc = 0, tot = 0;
-                for (int q = 0; q < nl; q++) {
-                    const double w = 1.0 + skew / 100.0 * (1.0 - 2.0 * q / (nl - 1));
-                    if (q < j) acc += w;
-                    tot += w;
-                }
-                return (uint64_t)(count * acc / tot + 0.5);
-            };
-            const uint64_t b = cut(k), e = k + 1 == nl ? count : cut(k + 1);
+            const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
             int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
             if (rc != PT_OK) return rc;
         }
