@@ -24,7 +24,6 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -637,7 +636,7 @@ static bool pack_shared_exponent(float4 c, uint32_t &word)
 template <class T>
 struct HostArray {
     T *p;
-    explicit HostArray(size_t n) : p((T *)std::calloc(std::max<size_t>(n, 1), sizeof(T))) {}
+    explicit HostArray(size_t n) : p((T *)std::malloc(std::max<size_t>(n, 1) * sizeof(T))) {}
     ~HostArray() { std::free(p); }
     HostArray(const HostArray &) = delete;
     HostArray &operator=(const HostArray &) = delete;
@@ -982,14 +981,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                                            : (bad[part] == 2 ? "leaf run leaves the triangle buffer" : "truncated triangle"));
         // record index of every run: nodes first, then the record nothing can hit, then the runs in node order
         std::vector<uint64_t> run_at(2 * N + 1);
-        static const bool leaf_align = std::getenv("PT_LEAF_ALIGN") != nullptr;     // experiment
-        uint64_t cursor = N + 1;
-        for (uint64_t k = 0; k < 2 * N; k++) {
-            if (leaf_align && run[k] == 2 && (cursor & 1)) cursor++;      // a pair of triangles in one 128 B line
-            run_at[k] = cursor;
-            cursor += run[k];
-        }
-        run_at[2 * N] = cursor;
+        run_at[0] = N + 1;
+        for (uint64_t k = 0; k < 2 * N; k++) run_at[k + 1] = run_at[k] + run[k];
         const uint64_t total_recs = run_at[2 * N];
         if (total_recs >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
         HostArray<float4> recs(total_recs * 4);
