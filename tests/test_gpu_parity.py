@@ -548,3 +548,26 @@ def test_full_size_frame_properties(pkg, ctx):
     ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2, nthreads=16)
     floor, _ = film_metrics(ofilm2, ofilm)
     assert differing <= MAX_FLIPPED_PATH_RATE * spp and rel_mse <= MAX_RELMSE_OVER_NOISE * floor, (differing, rel_mse, floor)
+
+
+def test_more_than_2_to_32_paths_in_one_call(pkg, ctx):
+    """The largest BASELINE configuration has 8.5 G camera paths (3840x2160x1024): path and ray counters are 64-bit, and a
+    call whose samples exceed the slab budget runs slab after slab.  Here 3840x2160x520 = 4.31 G paths (> 2^32) of the
+    spheres-only scene in one call: every path started exactly once, and the film equal to a 40-sample render of the same
+    scene within the noise of 40 samples."""
+    W, H, spp = 3840, 2160, 520
+    scene = S.spheres_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=9)
+    assert st.paths == W * H * spp and st.paths > 2 ** 32
+    assert st.rays > st.paths
+    big = ctx.film_download()
+    assert np.isfinite(big).all() and (big >= 0).all()
+    ctx.film_clear()
+    ctx.render(0, 40, 40, seed=9)
+    small = ctx.film_download()
+    # same estimator, fewer samples: the means agree closely, single pixels within the noise of 40 samples
+    assert abs(big.mean() - small.mean()) <= 0.01 * small.mean()
+    rel_mse, _ = film_metrics(small, big)
+    assert rel_mse <= 0.2, rel_mse
