@@ -3,7 +3,7 @@
 // One wavefront iteration advances every live path by one segment:
 //   bounce   (logic + shade: ends paths on miss / depth limit / Russian roulette, shades the survivors whatever their
 //             material and appends their continued rays, in input order, to the other path buffer; one atomic per
-//             512-thread block)
+//             block)
 //   generate (fills the rest of that buffer with new camera paths)
 //   advance  (one thread: rolls the device-side counters over)
 //   extend   (closest hit for every ray of the new buffer)
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
     // the trip count is the same for every thread of a block (barriers inside)
     for (uint32_t first = blockIdx.x * kBounceBlock; first < n; first += stride, par ^= 1) {
         const uint32_t i = first + threadIdx.x;
-        // the state of the block's next 512 rays is requested before this batch is shaded, so that the streaming loads
+        // the state of the block's next batch of rays is requested before this batch is shaded, so that the streaming loads
         // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
         const BounceIn in = nxt;
         nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u, n_front, P);
