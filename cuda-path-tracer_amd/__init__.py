@@ -133,6 +133,7 @@ def hip_lib():
         L.pt_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pt_intersect_device.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(Stats)]
+        L.pt_intersect_device_noalloc.argtypes = L.pt_intersect_device.argtypes
         L.pt_primary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p,
                                       C.c_void_p]
         L.pt_film_bind.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -344,6 +345,12 @@ class Context:
         """Device pointers (ints).  Returns Stats."""
         st = Stats()
         self._check(self._L.pt_intersect_device(self._h, n, d_org4, d_dir4, d_hit4, d_t, C.byref(st)))
+        return st
+
+    def intersect_device_noalloc(self, n, d_org4, d_dir4, d_hit4, d_t):
+        """intersect_device without any device allocation (static scratch, at most 4,194,304 rays).  Returns Stats."""
+        st = Stats()
+        self._check(self._L.pt_intersect_device_noalloc(self._h, n, d_org4, d_dir4, d_hit4, d_t, C.byref(st)))
         return st
 
     def primary_rays(self, width, height, sample=0, seed=0):

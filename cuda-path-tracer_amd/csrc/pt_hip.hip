@@ -25,6 +25,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -37,6 +38,7 @@ using namespace ptd;
 
 namespace {
 
+constexpr uint64_t kMaxRaysPerCall = 0xFFFFFFFFull - (1ull << 20);
 constexpr uint32_t kDefaultPool = 1u << 27;   // upper bound; a render uses no more slots than it has paths
 
 struct PathBuf {
@@ -469,9 +471,38 @@ __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint3
 
 }   // namespace
 
+// ---- device memory of the closest-hit entry point that allocates nothing (pt_intersect_device_noalloc) ---------------
+// One array per GPU, held from the moment the code object is loaded until the process ends: the call's counters in the
+// first 256 bytes, then one hit id per ray.  `scratch` is the host-side handle of the symbol, not a device address; host
+// code uses the per-device address hipGetSymbolAddress returns (scratch_on_device), never the name.
+constexpr uint64_t kNoAllocMaxRays = 1ull << 22;            // 4,194,304 rays per call: 16 MiB of hit ids
+constexpr size_t kScratchHeader = 256;
+constexpr int kNoAllocMaxStackSlots = 48;                   // the whole traversal stack in LDS: 48 KB per block
+static_assert(sizeof(Counters) <= kScratchHeader, "the counters must fit the scratch header");
+static __device__ __align__(256) unsigned char scratch[kScratchHeader + kNoAllocMaxRays * sizeof(uint32_t)];
+
 // ================================================================================================================
 // host side
 // ================================================================================================================
+
+// address of `scratch` on each device, resolved once per device (pt_ctx_create) with that device current
+static std::mutex g_scratch_mu;
+static std::vector<unsigned char *> g_scratch_ptr;
+
+static hipError_t scratch_on_device(int device, unsigned char **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr.size() <= (size_t)device) g_scratch_ptr.resize((size_t)device + 1, nullptr);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (unsigned char *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 // One independent wavefront loop (own stream, path buffers and counters) rendering a share of a slab's samples.  The
 // lanes of a context run side by side: the traversal kernel is bound by record fetches through the caches, bounce and
 // generate by streaming state through HBM, so one lane's extend runs beside another lane's bounce.  Measured on the
@@ -523,6 +554,7 @@ struct pt_ctx {
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
     size_t tmp_hid_n = 0;
+    unsigned char *scratch = nullptr;   // this device's copy of the static scratch array (pt_intersect_device_noalloc)
 
     // film
     float *film = nullptr;
@@ -685,12 +717,13 @@ template <class T> static int upload(pt_ctx *ctx, const std::vector<T> &v, const
 // CU holds are 160 KB / that (at most 8).  Trees needing more than ctx->lds_slots slots keep the rest in a global
 // array.  Measured on the 868 k-triangle stand-in (26 slots): 26 slots in LDS, 6 blocks per CU, beat 20 slots + overflow
 // at 8 blocks per CU by 3 %.
+// gstk == NULL: the whole stack in LDS, whatever its depth (the caller has checked that it fits); nothing is allocated.
 static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_on_device, int **gstk,
                          size_t *gstk_threads, const float4 *ro, const float4 *rd, uint32_t n_fixed, uint32_t n_upper,
                          uint32_t *hid, float *t)
 {
     const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
-    const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots);
+    const int lds_slots = gstk ? (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots) : (int)need;
     const bool overflow = need > (uint32_t)lds_slots;
     const int per_cu = std::max(1, std::min(ctx->extend_blocks, 160 / lds_slots));
     const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
@@ -712,7 +745,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.cnt3 = &cnt->trav[0];
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
-    a.gstk = *gstk;
+    a.gstk = gstk ? *gstk : nullptr;
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
@@ -831,6 +864,7 @@ int pt_ctx_create(int device, pt_ctx **out)
     CREATECHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATECHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    CREATECHK(scratch_on_device(device, &ctx->scratch));
     CREATECHK(hipMalloc(&ctx->cnt, sizeof(Counters)));
     CREATECHK(hipHostMalloc(&ctx->h_cnt, sizeof(Counters)));
     for (auto &ln : ctx->lanes) {
@@ -1125,7 +1159,8 @@ int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void 
     if (!ctx) return PT_ERR_ARG;
     if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_intersect_device: no scene uploaded");
     if (n == 0) return PT_OK;
-    if (n > 0xFFFFFFFFull) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: more than 2^32-1 rays in one call");
+    // the kernels walk the ray buffer with 32-bit cursors that step by up to 2^19 (grid stride) past the last ray
+    if (n > kMaxRaysPerCall) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: more than 2^32 - 2^20 rays in one call");
     if (!d_org4 || !d_dir4 || !d_hit4 || !d_t) return fail(ctx, PT_ERR_ARG, "pt_intersect_device: NULL buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->tmp_hid_n < n) {
@@ -1143,6 +1178,47 @@ int pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void 
                        (const float4 *)d_org4, (const float4 *)d_dir4, ctx->tmp_hid, (const float *)d_t, (uint32_t)n,
                        (float4 *)d_hit4);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, ctx->cnt, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        stats->rays = n; stats->iterations = 1; stats->extend_launches = 1;
+        stats->ms_total = ms; stats->ms_extend = ms; stats->ms_extend_busy = ms;
+        stats->nodes = ctx->h_cnt->trav[0]; stats->tris = ctx->h_cnt->trav[1]; stats->leaves = ctx->h_cnt->trav[2];
+    }
+    return PT_OK;
+}
+
+int pt_intersect_device_noalloc(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4, void *d_hit4, void *d_t,
+                                pt_stats *stats)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "pt_intersect_device_noalloc: no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (n > kNoAllocMaxRays)
+        return fail(ctx, PT_ERR_ARG, "pt_intersect_device_noalloc: %llu rays, the static scratch holds %llu per call",
+                    (unsigned long long)n, (unsigned long long)kNoAllocMaxRays);
+    if (!d_org4 || !d_dir4 || !d_hit4 || !d_t) return fail(ctx, PT_ERR_ARG, "pt_intersect_device_noalloc: NULL buffer");
+    if (ctx->sc.has_bvh && ctx->sc.stack_slots > (uint32_t)kNoAllocMaxStackSlots)
+        return fail(ctx, PT_ERR_ARG, "pt_intersect_device_noalloc: the tree needs %u stack slots per ray, LDS alone holds %d",
+                    ctx->sc.stack_slots, kNoAllocMaxStackSlots);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the device's one scratch array: counters first, then the hit ids.  It keeps the last call's contents; the
+    // counters must start at zero, every hit id the call reads is written by the traversal first.
+    Counters *cnt = (Counters *)ctx->scratch;
+    uint32_t *hid = (uint32_t *)(ctx->scratch + kScratchHeader);
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, kScratchHeader, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+    int rc = launch_extend(ctx, ctx->stream, cnt, false, nullptr, nullptr, (const float4 *)d_org4, (const float4 *)d_dir4,
+                           (uint32_t)n, (uint32_t)n, hid, (float *)d_t);
+    if (rc != PT_OK) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+    hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->sc,
+                       (const float4 *)d_org4, (const float4 *)d_dir4, hid, (const float *)d_t, (uint32_t)n,
+                       (float4 *)d_hit4);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_cnt, cnt, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);

@@ -155,6 +155,16 @@ int  pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir,
 int  pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4,
                          void *d_hit4, void *d_t, pt_stats *stats);
 
+/* pt_intersect_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit, but the
+ * call makes no hipMalloc / hipFree: its hit-id scratch and counters live in one static device array per GPU (16 MiB +
+ * 256 B, held by every GPU the library runs on until the process ends) and its traversal stacks in LDS only.
+ * Limits: n <= 4,194,304 rays per call and a tree of at most 47 levels (48 stack slots); beyond either the call returns
+ * PT_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race, whatever their
+ * contexts or streams. */
+int  pt_intersect_device_noalloc(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4,
+                                 void *d_hit4, void *d_t, pt_stats *stats);
+
 /* Camera rays of one sample index exactly as the generate stage produces them (reference src/render.cu:93-127),
  * written to host arrays of width*height*3 floats indexed by film pixel.  For parity checks. */
 int  pt_primary_rays(pt_ctx *ctx, uint32_t width, uint32_t height, uint64_t sample, uint64_t seed,
