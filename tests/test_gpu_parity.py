@@ -162,6 +162,66 @@ def test_render_matches_oracle(pkg, ctx, name):
     assert rmse <= 0.25 * rmse_noise, "tone-mapped RMSE %g vs noise %g" % (rmse, rmse_noise)
 
 
+# The two BASELINE.json configurations with a mesh and an .hdr map, loaded from their scene files exactly as the benchmark
+# and the command line load them: reference scene/dragon.scene (868,352-triangle stand-in for the unshipped dragon.obj,
+# forest.hdr stand-in) and scene/bunny.scene (the shipped bunny.obj, sunset.hdr stand-in with a small sun disc of radiance
+# 5e3, the case where the light-sampling pdf of reference src/render.cu:145-151 is most extreme).
+@pytest.mark.parametrize("name", ["dragon", "bunny"])
+def test_benchmark_scene_files_match_oracle(pkg, ctx, name):
+    W, H, spp = 96, 54, 8
+    scene = pkg.HostScene(S.scene_file(pkg, name), W, H)
+    assert scene.desc.num_tris == {"dragon": 868352, "bunny": 28576}[name]
+    ctx.upload(scene)
+    assert ctx.env_is_packed
+    # (a) closest hits on primary + bounced + axis-parallel rays: bit-equal
+    org, dir_ = S.ray_batch(scene, W, H, seed=12)
+    t, prim, nrm = ctx.intersect(org, dir_, want_normals=True)
+    ot, oprim, onrm, _ = O.intersect(S.as_oracle_desc(scene), org, dir_, want_normals=True)
+    check_hits(t, prim, ot, oprim, name)
+    assert np.array_equal(t, ot)
+    assert np.allclose(nrm, onrm, rtol=0, atol=1e-6)
+    assert (prim != O.PRIM_MISS).mean() > 0.3
+    # (b) a small render against the oracle, same bars as test_render_matches_oracle
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=5)
+    film = ctx.film_download()
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
+    assert st.paths == W * H * spp == ost.paths
+    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
+    assert np.isfinite(ofilm).all() and np.isfinite(film).all() and (film >= 0).all()
+    rel_mse, differing = film_metrics(film, ofilm)
+    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
+    floor, _ = film_metrics(ofilm2, ofilm)
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
+
+
+@pytest.mark.parametrize("name", ["dragon", "bunny"])
+def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
+    """(c) 1920x1080 at 2 spp, the benchmark's frame size: every path started once, the film finite and non-negative
+    (a 0/0 from reference src/render.cu:145-151 would show here), the samples split over two calls equal to one call up to
+    float addition order, and the ray count the sum over both halves."""
+    W, H, spp = 1920, 1080, 2
+    scene = pkg.HostScene(S.scene_file(pkg, name), W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=1)
+    full = ctx.film_download()
+    assert st.paths == W * H * spp
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert full.mean() > 1e-3
+    acc = np.zeros_like(full)
+    rays = 0
+    for r in range(2):
+        b, c = pkg.spp_partition(spp, 2, r)
+        ctx.film_clear()
+        s2 = ctx.render(b, c, spp, seed=1)
+        rays += s2.rays
+        acc += ctx.film_download()
+    assert rays == st.rays
+    assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
+
+
 def test_render_matches_frozen_film(pkg, ctx):
     """Same bar as above against the film frozen in tests/golden/film_knot.npz (no oracle run involved)."""
     g = np.load(os.path.join(GOLDEN, "film_knot.npz"))
