@@ -19,6 +19,7 @@ OPT_TUNE_REFILL_IDLE, OPT_TUNE_LDS_SLOTS = 6, 7
 OPT_ENV_PACK = 8
 OPT_STREAMS = 9
 OPT_TUNE_EXTEND_BLOCKS = 10
+OPT_NODE_LAYOUT = 11
 
 
 class Plane(C.Structure):

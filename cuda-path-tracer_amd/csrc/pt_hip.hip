@@ -550,6 +550,7 @@ struct pt_ctx {
     int lds_slots = 26;
     int extend_blocks = 8;     // cap on extend blocks per CU (the LDS stacks usually allow fewer)
     bool env_pack = true;      // use the packed environment texels when they are exact
+    int node_layout = 1;       // 0: inner nodes in the order given, 1: parent + favoured child share a 128 B line
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
@@ -837,6 +838,68 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     return PT_OK;
 }
 
+// Record index of every inner node.  Layout 0 keeps the order given (the reference's flatten order, src/bvh.cu:234-294).
+// Layout 1 pairs nodes so that a node and the child a ray is most likely to visit next share one 128 B cache line: the
+// traversal fetches 64 B records, the caches fill 128 B lines, and with the order given the other half of a line is
+// rarely the record the ray needs next.  Top-down greedy matching: a node at the head of a line takes its inner child
+// with the larger box area (the chance that a ray through the parent's box hits the child's is proportional to it) as
+// the tail of the line; the other child and the tail's children head lines of their own.  Pairs come first, in
+// depth-first order (the root at record 0), then the nodes left single, two to a line, then anything unreachable.
+// Only indices change: visit order and arithmetic of the traversal are the same, so are its answers.
+// Returns false when the child references do not form a tree.
+static bool node_layout_pairs(const float *nodes, uint64_t N, std::vector<uint32_t> &newid)
+{
+    const uint32_t none = 0xFFFFFFFFu;
+    newid.assign(N, none);
+    auto child = [&](uint64_t i, int c) { int32_t v; std::memcpy(&v, nodes + i * 16 + 12 + c, 4); return v; };
+    auto half_area = [&](uint64_t i, int c) {
+        const float *n = nodes + i * 16;
+        const float dx = n[4 * c + 1] - n[4 * c], dy = n[4 * c + 3] - n[4 * c + 2], dz = n[8 + 2 * c + 1] - n[8 + 2 * c];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // pass 1: the matching, depth first.  state: 1 head of a pair, 2 tail, 3 single
+    std::vector<uint8_t> state(N, 0);
+    std::vector<uint32_t> order;            // heads and singles in depth-first order
+    order.reserve(N);
+    std::vector<uint32_t> tail_of(N, none);
+    std::vector<uint32_t> st;
+    st.push_back(0);
+    uint64_t seen = 0;
+    while (!st.empty()) {
+        const uint32_t p = st.back();
+        st.pop_back();
+        if (state[p]) return false;
+        if (++seen > N) return false;
+        const int32_t c0 = child(p, 0), c1 = child(p, 1);
+        const bool in0 = c0 > 0, in1 = c1 > 0;
+        order.push_back(p);
+        if (!in0 && !in1) { state[p] = 3; continue; }
+        int fav = in0 ? 0 : 1;
+        if (in0 && in1 && half_area(p, 1) > half_area(p, 0)) fav = 1;
+        const uint32_t f = (uint32_t)(fav ? c1 : c0);
+        if (state[f]) return false;
+        if (++seen > N) return false;
+        state[p] = 1;
+        state[f] = 2;
+        tail_of[p] = f;
+        // pushed last = visited first: the tail's children, then the head's other child
+        const int32_t o = fav ? c0 : c1;
+        if (o > 0) st.push_back((uint32_t)o);
+        const int32_t f0 = child(f, 0), f1 = child(f, 1);
+        if (f1 > 0) st.push_back((uint32_t)f1);
+        if (f0 > 0) st.push_back((uint32_t)f0);
+    }
+    // pass 2: positions
+    uint32_t pos = 0;
+    for (uint32_t p : order)
+        if (state[p] == 1) { newid[p] = pos++; newid[tail_of[p]] = pos++; }
+    for (uint32_t p : order)
+        if (state[p] == 3) newid[p] = pos++;
+    for (uint64_t i = 0; i < N; i++)
+        if (newid[i] == none) newid[i] = pos++;
+    return pos == N && newid[0] == 0;
+}
+
 extern "C" {
 
 int pt_ctx_create(int device, pt_ctx **out)
@@ -962,6 +1025,10 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         ctx->extend_blocks = (int)value;
         return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
+    case PT_OPT_NODE_LAYOUT:
+        if (value > 1) return fail(ctx, PT_ERR_ARG, "node layout %llu unknown", (unsigned long long)value);
+        ctx->node_layout = (int)value;
+        return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
 }
@@ -1029,15 +1096,23 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             std::memcpy(&meta, m, 8);
             nohit[3] = meta;
         }
+        // where every inner node goes (see node_layout_pairs)
+        std::vector<uint32_t> newid;
+        if (ctx->node_layout == 1) {
+            if (!node_layout_pairs(s->bvh_nodes, N, newid)) return fail(ctx, PT_ERR_ARG, "node graph is not a tree");
+        } else {
+            newid.resize(N);
+            for (uint64_t i = 0; i < N; i++) newid[i] = (uint32_t)i;
+        }
         // Pass 2: node records with their child references rewritten, triangle records with id and flags
         parallel_chunks(N, bad.size(), [&](size_t, uint64_t lo, uint64_t hi) {
             for (uint64_t i = lo; i < hi; i++) {
-                float4 *node = recs.p + i * 4;
+                float4 *node = recs.p + (size_t)newid[i] * 4;
                 std::memcpy(node, s->bvh_nodes + i * 16, 64);
                 int32_t ch[2];
                 std::memcpy(ch, &node[3], 8);
                 for (int c = 0; c < 2; c++) {
-                    if (ch[c] >= 0) continue;
+                    if (ch[c] >= 0) { ch[c] = (int32_t)newid[ch[c]]; continue; }
                     const uint64_t count = run[2 * i + c];
                     if (count == 0) { ch[c] = (int32_t)N; continue; }
                     uint64_t a = (uint64_t)(uint32_t)~ch[c];
