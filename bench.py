@@ -10,12 +10,19 @@ and the float films are summed onto rank 0 with one reduce (RCCL); the reduce is
 is fixed, so scaling is "strong".  One ray = one closest-hit query.
 
 The JSON line also carries
-  roofline      the extend (traversal) kernel against the 8 TB/s HBM peak: algorithmic bytes per ray (120 B of path
-                state + 64 B per inner node visited + 48 B per triangle tested + 16 B per leaf entered, the per-ray
-                means counted by the CPU oracle on a reduced-resolution run of the same scene) times the rays of the
-                timed steps, divided by the HIP-event time of the extend launches on the library's own stream;
+  roofline      the extend (traversal) kernel against the 8 TB/s HBM peak.  achieved = algorithmic bytes per launch (120 B
+                of path state + 64 B per inner node visited + 48 B per triangle tested + 16 B per leaf entered, the
+                per-ray means counted by the CPU oracle on a reduced-resolution run of the same scene, times the rays the
+                launch traces) divided by the mean HIP-event duration of the non-empty extend launches, measured on the
+                library's own streams.  The tree is served by L1/L2/Infinity Cache, so these are not HBM bytes: the block
+                also carries what the counters say (traffic = fabric-side bytes per launch from committed rocprofv3
+                --pmc passes of this command, with cache hit rates and lane utilisation from the same passes) and the
+                kernel's record fetch rate against the rate a bare dependent-gather probe reaches at the same hit mix.
   cpu_baseline  the CPU oracle (a host restatement of the reference's traversal and shading) timed on this machine's
                 cores on a bounded sample of the same workload (960x540, 320 spp).
+  film_check    the film of the last timed frame: finite everywhere, and its mean next to the mean of the oracle's film
+                of the bounded sample (same camera and scene at a quarter of the pixels); the run fails when they differ
+                by more than 2 %.
 """
 import argparse
 import json
@@ -113,7 +120,7 @@ def main():
         acc["rays_escaped"] += st.rays_escaped
         acc["ms_extend"] += st.ms_extend
         acc["ms_extend_busy"] += st.ms_extend_busy
-        acc["launches"] += st.iterations
+        acc["launches"] += st.extend_launches
         acc["ms_render"] += st.ms_total
         return st
 
@@ -137,13 +144,18 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # whole-job numbers: max time over ranks, rays summed over ranks
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rr = torch.tensor([float(acc["rays"])], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, acc["ms_extend_busy"], acc["ms_render"]], dtype=torch.float64, device=dev)
+    keys = ["rays", "rays_escaped", "ms_extend", "launches"]
+    rr = torch.tensor([float(acc[k]) for k in keys], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    total_rays = float(rr.item())
+    elapsed = float(tt[0].item())
+    # rays, launches and the launches' summed durations over all ranks; busy and render time of the slowest rank
+    acc.update({k: float(v) for k, v in zip(keys, rr.tolist())})
+    acc["ms_extend_busy"], acc["ms_render"] = float(tt[1].item()), float(tt[2].item())
+    total_rays = acc["rays"]
+    film_host = film.cpu().numpy() if rank == 0 else None
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(1, args.steps)
@@ -174,13 +186,16 @@ def main():
         # CPU oracle on a bounded sample: gives the baseline and the per-ray traversal means for the roofline
         cpu = None
         b_ray = None
+        oracle_mean = None
+        trav = None
         if not args.no_cpu_baseline and world == 1:
             import oracle_lib as O
 
             cw, ch, cspp = 960, 540, 320      # about 10 s on 16 cores
             cscene = make_scene(cw, ch)
             threads = min(os.cpu_count() or 1, 16)
-            _, ost = O.render(S.as_oracle_desc(cscene), cw, ch, 0, cspp, cspp, seed=1, nthreads=threads)
+            ofilm, ost = O.render(S.as_oracle_desc(cscene), cw, ch, 0, cspp, cspp, seed=1, nthreads=threads)
+            oracle_mean = float(ofilm.astype(np.float64).mean())
             cpu = {
                 "value": round(ost.rays / ost.ms / 1e3, 3),
                 "unit": "Mrays/s",
@@ -189,51 +204,86 @@ def main():
                 "sample": "%s.scene %dx%d %d spp: %d rays in %.0f ms" % (args.scene, cw, ch, cspp, ost.rays, ost.ms),
             }
             b_ray = B_STATE + (64.0 * ost.nodes + 48.0 * ost.tris + 16.0 * ost.leaves) / max(1, ost.rays)
+            trav = (ost.nodes / ost.rays, ost.tris / ost.rays)
             out["config"]["traversal_means"] = {"nodes": round(ost.nodes / ost.rays, 3),
                                                 "tris": round(ost.tris / ost.rays, 3),
                                                 "leaves": round(ost.leaves / ost.rays, 3),
                                                 "bytes_per_ray": round(b_ray, 1)}
         out["cpu_baseline"] = cpu
-        # HBM-side bytes per extend launch, from committed rocprofv3 --pmc passes of this same command (not collected here:
-        # counter collection needs its own profiler runs); null when the summary is absent or is for another workload
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r1_extend_traffic.json")
-        if os.path.exists(tpath) and args.scene == "dragon" and (args.width, args.height, args.spp) == (1920, 1080, 512):
-            prof = json.load(open(tpath))
-            if world == 1:
-                traffic = prof.get("traffic_bytes_per_launch")
+        # The film of the last timed frame (on rank 0 after the reduce): it must be finite, and its mean must agree with the
+        # oracle's film of the bounded sample.
+        finite = bool(np.isfinite(film_host).all())
+        film_mean = float(film_host.astype(np.float64).mean())
+        out["film_check"] = {"finite": finite, "min": float(film_host.min()), "mean": round(film_mean, 6),
+                             "oracle_mean": None if oracle_mean is None else round(oracle_mean, 6),
+                             "rel_diff": None if oracle_mean is None else round(abs(film_mean - oracle_mean) / oracle_mean, 5)}
+        # Counter-side figures of the extend kernel, from the committed rocprofv3 --pmc passes of this same command (not
+        # collected here: counters need profiler runs of their own); null when absent or for another workload
+        prof = None
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_extend_traffic.json"))
+        if cands and args.scene == "dragon" and (args.width, args.height, args.spp) == (1920, 1080, 512):
+            prof = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
+            prof["file"] = "profiles/" + cands[-1]
             if b_ray is None:
                 # the oracle's per-ray traversal means of this workload are deterministic; without the CPU leg (N > 1 or
-                # --no-cpu-baseline) the committed figure of the same workload is used
+                # --no-cpu-baseline) the committed figures of the same workload are used
                 b_ray = prof.get("algorithmic_bytes_per_ray")
-        if b_ray is not None and acc["ms_extend"] > 0:
-            # b_ray is the mean over ALL rays.  Rays that escaped where they were created (one root visit in the oracle's
-            # count) never reach an extend launch, so their bytes are taken out of what the extend launches are credited with.
+                trav = (prof.get("nodes_per_ray"), prof.get("tris_per_ray"))
+        if b_ray is not None and acc["ms_extend"] > 0 and acc["launches"] > 0:
+            # b_ray is the mean over ALL rays.  Rays that were settled where they were created (one root visit in the
+            # oracle's count) never reach an extend launch, so their bytes are taken out of what the launches are credited with.
             has_tree = int(scene.desc.num_nodes) > 0
             ext_bytes = b_ray * acc["rays"] - acc["rays_escaped"] * (B_STATE + (64.0 if has_tree else 0.0))
             ext_rays = acc["rays"] - acc["rays_escaped"]
+            launches = acc["launches"]
+            avg_ms = acc["ms_extend"] / launches
             achieved = ext_bytes / (acc["ms_extend"] * 1e-3) / 1e9
+            traffic = prof.get("traffic_bytes_per_launch") if (prof and world == 1) else None
             out["config"]["rays_escaped_at_creation_per_frame"] = int(acc["rays_escaped"] / max(1, args.steps))
-            out["roofline"] = {
+            roof = {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_extend",
-                "avg_launch_ms": round(acc["ms_extend"] / max(1, acc["launches"]), 4),
-                "launches": int(acc["launches"]),
-                "rays_per_launch": round(ext_rays / max(1, acc["launches"]), 1),
-                "bytes_per_launch": round(ext_bytes / max(1, acc["launches"]), 0),
+                "kernel": "k_extend_stream",
+                "launches": int(launches),
+                "avg_launch_ms": round(avg_ms, 4),
+                "rays_per_launch": round(ext_rays / launches, 1),
+                "bytes_per_launch": round(ext_bytes / launches, 0),
                 # The library runs several wavefront loops on streams of their own, so extend launches overlap each other
-                # (and the other kernels): a launch then has only part of the device and its own duration understates what
-                # the device does.  achieved_all_streams divides the same bytes by the time during which at least one
-                # extend launch was running.
+                # and the other kernels; a launch's duration is then longer than it would be alone.
                 "concurrent_streams": streams,
-                "achieved_all_streams": round(ext_bytes / (acc["ms_extend_busy"] * 1e-3) / 1e9, 1),
-                "frac_all_streams": round(ext_bytes / (acc["ms_extend_busy"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "extend_busy_share_of_frame": round(acc["ms_extend_busy"] / max(1e-9, acc["ms_render"]), 3),
+                # rays that enter an extend launch (the ones a tree is traversed for) per second of frame time
+                "traversed_mrays_per_s": round(ext_rays / elapsed / 1e6, 1),
             }
+            if trav and trav[0] is not None:
+                # 64 B records the launches fetch: every node visit and triangle test of the rays they trace
+                recs = (trav[0] + trav[1]) * acc["rays"] - acc["rays_escaped"] * (1.0 if has_tree else 0.0)
+                roof["records_per_s"] = round(recs / (acc["ms_extend_busy"] * 1e-3), 0)
+            if prof:
+                roof["counters"] = {
+                    "source": prof["file"],
+                    # fabric-side bytes per launch over the launch's duration IN THE COUNTER RUN (launches serialised there)
+                    "achieved_traffic": prof.get("achieved_traffic_gbs"),
+                    "frac_traffic": None if prof.get("achieved_traffic_gbs") is None
+                    else round(prof["achieved_traffic_gbs"] / HBM_PEAK_GBS, 4),
+                    "traffic_over_algorithmic": None if not traffic else round(traffic * launches / ext_bytes, 4),
+                    "l2_hit_rate": prof.get("l2_hit_rate"),
+                    "l1_hit_share_of_records": prof.get("l1_hit_share"),
+                    "active_lane_fraction": prof.get("active_lane_fraction"),
+                    "valu_busy": prof.get("valu_busy"),
+                    "waves_waiting": prof.get("waves_waiting"),
+                    # what a bare dependent-gather kernel reaches on this GPU at the same L1 / L2 / fabric mix
+                    "record_rate_ceiling": prof.get("record_rate_ceiling"),
+                    "frac_of_record_rate_ceiling": None if not (prof.get("record_rate_ceiling") and roof.get("records_per_s"))
+                    else round(roof["records_per_s"] / prof["record_rate_ceiling"], 4),
+                }
+            out["roofline"] = roof
         else:
             out["roofline"] = None
         print(json.dumps(out), flush=True)
+        fc = out["film_check"]
+        if not fc["finite"] or fc["min"] < 0 or (fc["rel_diff"] is not None and fc["rel_diff"] > 0.02):
+            raise SystemExit("bench: the film of the timed frame fails its check: %r" % (fc,))
 
     ctx.close()
     if world > 1:

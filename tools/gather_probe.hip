@@ -4,7 +4,9 @@
 //           cover the quad's four records, then a 4x4 transpose inside the quad gives every lane its record
 //   mode 2  as mode 1 without the transpose (upper bound of what the load side can gain; results meaningless)
 // Every lane walks a pseudo-random chain: next index = hash(sum of the record's words) so loads depend on each other.
-// usage: gather_probe [records] [steps] [lds_bytes_per_block]
+// usage: gather_probe [records] [steps] [lds_bytes_per_block] [active_lanes]
+// active_lanes < 64 (mode 0 only): the other lanes of every wave sit out (exec-masked), as lanes without a ray do in the
+// traversal kernel; the rate then tells whether the fetch path is priced per instruction or per active lane.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -51,13 +53,15 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], uint32_t lane)
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_probe(const float4 *__restrict__ recs, uint32_t nrec, int steps, uint32_t *out)
+__global__ __launch_bounds__(256) void k_probe(const float4 *__restrict__ recs, uint32_t nrec, int steps, uint32_t *out,
+                                               uint32_t active)
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t idx = mix(gid) % nrec;
     uint32_t acc = 0;
     if (lds[threadIdx.x] == 12345) acc = 1;      // keep the LDS allocation
+    if (MODE == 0 && lane >= active) { out[gid] = 0; return; }
     for (int s = 0; s < steps; s++) {
         float4 r[4];
         if (MODE == 0) {
@@ -98,6 +102,7 @@ int main(int argc, char **argv)
     const uint32_t nrec = argc > 1 ? atoi(argv[1]) : 1300000;
     const int steps = argc > 2 ? atoi(argv[2]) : 2000;
     const int lds_bytes = argc > 3 ? atoi(argv[3]) : 26 * 1024;
+    const uint32_t active = argc > 4 ? atoi(argv[4]) : 64;
     std::vector<uint32_t> h((size_t)nrec * 16);
     uint32_t s = 1;
     for (auto &v : h) { s = s * 1664525u + 1013904223u; v = s; }
@@ -109,16 +114,16 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> res0((size_t)blocks * 256), res1(res0.size());
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < (active < 64 ? 1 : 3); mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out);
-            if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out);
-            if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out);
+            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
+            if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
+            if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
-            const double fetches = (double)blocks * 256 * steps;
+            const double fetches = (double)blocks * 256 * steps * (mode == 0 ? active / 64.0 : 1.0);
             if (rep) printf("mode %d: %8.3f ms  %7.2f G records/s  %7.1f GB/s\n", mode, ms, fetches / ms * 1e-6, fetches * 64 / ms * 1e-6);
         }
         if (mode == 0) CHECK(hipMemcpy(res0.data(), out, res0.size() * 4, hipMemcpyDeviceToHost));
