@@ -38,6 +38,10 @@ class Camera(C.Structure):
                 ("lens_radius", C.c_float)]
 
 
+class Mesh(C.Structure):
+    _fields_ = [("material", C.c_float * 4), ("material_type", C.c_uint32), ("first_face", C.c_uint32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("bvh_nodes", C.c_void_p), ("num_nodes", C.c_uint64),
                 ("bvh_tris", C.c_void_p), ("num_tri_float4", C.c_uint64),
@@ -47,7 +51,8 @@ class SceneDesc(C.Structure):
                 ("spheres", C.c_void_p), ("num_spheres", C.c_uint64),
                 ("camera", Camera),
                 ("env_width", C.c_uint32), ("env_height", C.c_uint32),
-                ("env_texels", C.c_void_p), ("env_marginal", C.c_void_p), ("env_conditional", C.c_void_p)]
+                ("env_texels", C.c_void_p), ("env_marginal", C.c_void_p), ("env_conditional", C.c_void_p),
+                ("meshes", C.c_void_p), ("num_meshes", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -180,7 +185,9 @@ class ManualScene:
     """A scene built from numpy buffers (planes, spheres, BVH buffers, environment) rather than from a file."""
 
     def __init__(self, camera, env_texels, env_marginal, env_conditional, planes=(), spheres=(), bvh=None,
-                 mesh_material=(0.7, 0.7, 0.7, 0.0), mesh_material_type=DIFFUSE):
+                 mesh_material=(0.7, 0.7, 0.7, 0.0), mesh_material_type=DIFFUSE, meshes=None):
+        """meshes: optional list of (material, material_type, first_face): several meshes in the one BVH, each with its
+        own material (a triangle belongs to the last mesh whose first_face <= its prim id)."""
         d = SceneDesc()
         self._keep = []
         if bvh is not None:
@@ -193,6 +200,10 @@ class ManualScene:
             d.bvh_prim_ids, d.num_tris = ids.ctypes.data, int(bvh["num_tris"])
         d.mesh_material = (C.c_float * 4)(*mesh_material)
         d.mesh_material_type = mesh_material_type
+        if meshes:
+            arr = (Mesh * len(meshes))(*[Mesh((C.c_float * 4)(*m), t, f) for m, t, f in meshes])
+            self._keep.append(arr)
+            d.meshes, d.num_meshes = C.addressof(arr), len(meshes)
         if planes:
             arr = (Plane * len(planes))(*planes)
             self._keep.append(arr)

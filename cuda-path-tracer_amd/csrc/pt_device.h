@@ -70,10 +70,12 @@ __device__ __forceinline__ void st_stream(uint32_t *p, uint32_t v) { __builtin_n
 // ---- scene as the kernels see it ----------------------------------------------------------------------------
 struct DPlane { float4 pos; float4 nrm; float4 mat; uint32_t type; uint32_t pad[3]; };    // 64 B
 struct DSphere { float4 pos_r; float4 mat; uint32_t type; uint32_t pad[3]; };            // 48 B
+struct DMesh { float4 mat; uint32_t type; uint32_t pad[3]; };                             // 32 B
 
 struct DScene {
     // 64 B records.  [0, first_tri): inner nodes = left xy box, right xy box, both z ranges, (left ref, right ref, 0, 0);
-    // [first_tri, ...): triangles = Woop rows z, x, y and (prim id, flags: 1 = last of its leaf, 2 = null record, 0, 0).
+    // [first_tri, ...): triangles = Woop rows z, x, y and (prim id, flags: 1 = last of its leaf, 2 = null record,
+    // index of the triangle's mesh, 0).
     // A ref is a record index; refs >= first_tri are leaves.
     const float4 *recs;
     uint32_t first_tri;
@@ -81,7 +83,9 @@ struct DScene {
     const DPlane *planes;
     const DSphere *spheres;
     uint32_t num_planes, num_spheres, has_bvh, mesh_type;
-    float4 mesh_mat;
+    float4 mesh_mat;         // material of the mesh when the scene has one mesh (num_meshes <= 1)
+    const DMesh *meshes;     // per-mesh materials when it has several, indexed by the triangle record's mesh word
+    uint32_t num_meshes;
     const float4 *env;       // [envH][envW] rgb + pdf, or NULL when envp is used
     // Packed form of the same texels: rgb as one shared-exponent word (exact: chosen only when every texel of the map
     // is a value such a word can hold, as maps decoded from Radiance .hdr files are) + the pdf, 8 B per texel in 4x4

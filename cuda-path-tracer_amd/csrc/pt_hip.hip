@@ -19,11 +19,15 @@
 // pixel in sample order and adds the sum to the film, so the film is reproducible bit for bit from run to run and
 // independent of pool size and kernel scheduling.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -73,17 +77,25 @@ __device__ __forceinline__ int mat_slot(uint32_t type)
     return type == PT_DIFFUSE ? 0 : (type == PT_GLOSSY ? 1 : (type == PT_MIRROR ? 2 : (type == PT_GLASS ? 3 : 0)));
 }
 
-__device__ __forceinline__ uint32_t material_type_of(const DScene &sc, uint32_t prim)
+// Material of a hit (reference src/render.cu:21-23,33-38: intersect_scene hands material and type on with the hit).
+// hid: PT_PRIM_PLANE | i, PT_PRIM_SPHERE | i, or the record index of a triangle.  A scene with one mesh keeps its
+// material in the scene constants; with several meshes the triangle record names its mesh.
+__device__ __forceinline__ void material_of(const DScene &sc, uint32_t hid, float4 &mat, uint32_t &type)
 {
-    if (prim & PT_PRIM_PLANE) return sc.planes[prim & 0x3FFFFFFFu].type;
-    if (prim & PT_PRIM_SPHERE) return sc.spheres[prim & 0x3FFFFFFFu].type;
-    return sc.mesh_type;
-}
-__device__ __forceinline__ float4 material_of(const DScene &sc, uint32_t prim)
-{
-    if (prim & PT_PRIM_PLANE) return sc.planes[prim & 0x3FFFFFFFu].mat;
-    if (prim & PT_PRIM_SPHERE) return sc.spheres[prim & 0x3FFFFFFFu].mat;
-    return sc.mesh_mat;
+    if (hid & PT_PRIM_PLANE) {
+        mat = sc.planes[hid & 0x3FFFFFFFu].mat;
+        type = sc.planes[hid & 0x3FFFFFFFu].type;
+    } else if (hid & PT_PRIM_SPHERE) {
+        mat = sc.spheres[hid & 0x3FFFFFFFu].mat;
+        type = sc.spheres[hid & 0x3FFFFFFFu].type;
+    } else if (sc.num_meshes <= 1) {
+        mat = sc.mesh_mat;
+        type = sc.mesh_type;
+    } else {
+        const DMesh &m = sc.meshes[__float_as_uint(sc.recs[(size_t)hid * 4 + 3].z)];
+        mat = m.mat;
+        type = m.type;
+    }
 }
 
 // What a path adds to its pixel if its current ray leaves the scene or is cut at the depth limit: throughput times the
@@ -280,8 +292,10 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
         float nt = kFltMax;
         uint32_t nhid = PT_PRIM_MISS;
         if (alive) {
-            const float4 mat = material_of(sc, hid);
-            const int slot = mat_slot(material_type_of(sc, hid));
+            float4 mat;
+            uint32_t mat_type;
+            material_of(sc, hid, mat, mat_type);
+            const int slot = mat_slot(mat_type);
             const f3 o = xyz(o4), d = xyz(d4);
             uint32_t prim;
             const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
@@ -532,6 +546,7 @@ struct Lane {
 
 struct pt_ctx {
     int device = 0;
+    bool counted = false;          // included in g_live_contexts
     hipStream_t stream = nullptr;
     std::string err;
     int num_cus = 256;
@@ -809,6 +824,7 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
                        ln.slab);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u,
                        ln.d_done);
+    HIPCHK(ctx, hipGetLastError());         // of the four launches above
     if (ctx->time_extend) {
         while (ln.events.size() < ln.ev_used + 2) {
             hipEvent_t ev;
@@ -837,6 +853,116 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     }
     return PT_OK;
 }
+
+// Error exit of pt_render: waits for whatever the lanes have queued, so that the context's buffers are quiet when the
+// caller sees the error and the next call starts from a defined state.
+static int drain_lanes(pt_ctx *ctx, int rc)
+{
+    for (auto &ln : ctx->lanes) {
+        if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        ln.done = true;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+    return rc;
+}
+
+// ---- RCCL, bound at first use ------------------------------------------------------------------------------------
+// pt_film_reduce is the library's only collective and only a process that drives several GPUs calls it, so the library
+// does not link against RCCL: the few entry points are looked up when the first reduce over distinct devices runs.  A
+// communicator set is kept per device list (creating one takes far longer than a reduce) until the last context of
+// the process is destroyed.
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;      // why it is unavailable
+    bool tried = false;
+};
+
+struct CommSet {
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+std::vector<CommSet> g_comm_sets;
+int g_live_contexts = 0;
+
+bool rccl_load()
+{
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { g_rccl.why = "librccl.so.1 not found"; return false; }
+#define PT_SYM(field, sym)                                                       \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.lib, sym);               \
+    if (!g_rccl.field) { g_rccl.why = std::string("RCCL lacks ") + sym; g_rccl.lib = nullptr; return false; }
+    PT_SYM(CommInitAll, "ncclCommInitAll")
+    PT_SYM(CommDestroy, "ncclCommDestroy")
+    PT_SYM(Reduce, "ncclReduce")
+    PT_SYM(GroupStart, "ncclGroupStart")
+    PT_SYM(GroupEnd, "ncclGroupEnd")
+    PT_SYM(GetErrorString, "ncclGetErrorString")
+#undef PT_SYM
+    return true;
+}
+
+void rccl_drop_all()
+{
+    for (auto &cs : g_comm_sets)
+        for (ncclComm_t c : cs.comms) (void)g_rccl.CommDestroy(c);
+    g_comm_sets.clear();
+}
+
+// One ncclReduce(sum, f32) of the films onto ctxs[root], every rank on its own context's stream.
+int film_reduce_rccl(pt_ctx *const *ctxs, int n, int root, uint64_t count)
+{
+    pt_ctx *dst = ctxs[root];
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (!rccl_load()) return fail(dst, PT_ERR_STATE, "pt_film_reduce: %s", g_rccl.why.c_str());
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+    CommSet *cs = nullptr;
+    for (auto &c : g_comm_sets)
+        if (c.devices == devs) cs = &c;
+    if (!cs) {
+        CommSet fresh;
+        fresh.devices = devs;
+        fresh.comms.resize(n);
+        const ncclResult_t r = g_rccl.CommInitAll(fresh.comms.data(), n, devs.data());
+        if (r != ncclSuccess) return fail(dst, PT_ERR_HIP, "ncclCommInitAll: %s", g_rccl.GetErrorString(r));
+        g_comm_sets.push_back(fresh);
+        cs = &g_comm_sets.back();
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; i++) {
+        if (hipSetDevice(ctxs[i]->device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+        // in place on the root; the other ranks' receive buffers are not written
+        r = g_rccl.Reduce(ctxs[i]->film, ctxs[i]->film, count, ncclFloat32, ncclSum, root, cs->comms[i], ctxs[i]->stream);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return fail(dst, PT_ERR_HIP, "ncclReduce: %s", g_rccl.GetErrorString(r));
+    for (int i = 0; i < n; i++) {
+        HIPCHK(dst, hipSetDevice(ctxs[i]->device));
+        HIPCHK(dst, hipStreamSynchronize(ctxs[i]->stream));
+    }
+    HIPCHK(dst, hipSetDevice(dst->device));
+    return PT_OK;
+}
+
+}   // namespace
 
 // Record index of every inner node.  Layout 0 keeps the order given (the reference's flatten order, src/bvh.cu:234-294).
 // Layout 1 pairs nodes so that a node and the child a ray is most likely to visit next share one 128 B cache line: the
@@ -943,6 +1069,11 @@ int pt_ctx_create(int device, pt_ctx **out)
     CREATECHK(hipEventCreate(&ctx->ev_end));
     CREATECHK(hipEventCreateWithFlags(&ctx->ev_slab_free, hipEventDisableTiming));
 #undef CREATECHK
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mu);
+        g_live_contexts++;
+    }
+    ctx->counted = true;
     *out = ctx;
     return PT_OK;
 }
@@ -950,6 +1081,11 @@ int pt_ctx_create(int device, pt_ctx **out)
 void pt_ctx_destroy(pt_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->counted) {
+        // the communicators go with the last context of the process
+        std::lock_guard<std::mutex> lock(g_rccl_mu);
+        if (--g_live_contexts == 0) rccl_drop_all();
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &ln : ctx->lanes) {
@@ -1036,6 +1172,32 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
 int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
 {
     if (!ctx || !s) return PT_ERR_ARG;
+    // arguments first: nothing is allocated or freed for a scene that is refused (reference src/scene.cu:132 prints
+    // "Invalid material type" for a type it does not know)
+    auto known_type = [](uint32_t t) { return t == PT_DIFFUSE || t == PT_MIRROR || t == PT_GLOSSY || t == PT_GLASS; };
+    if (s->num_planes >= (1u << 30) || s->num_spheres >= (1u << 30)) return fail(ctx, PT_ERR_ARG, "too many primitives");
+    if ((s->num_planes && !s->planes) || (s->num_spheres && !s->spheres))
+        return fail(ctx, PT_ERR_ARG, "pt_scene_upload: primitive count without primitive array");
+    for (uint64_t i = 0; i < s->num_planes; i++)
+        if (!known_type(s->planes[i].material_type))
+            return fail(ctx, PT_ERR_ARG, "plane %llu: invalid material type 0x%x", (unsigned long long)i, s->planes[i].material_type);
+    for (uint64_t i = 0; i < s->num_spheres; i++)
+        if (!known_type(s->spheres[i].material_type))
+            return fail(ctx, PT_ERR_ARG, "sphere %llu: invalid material type 0x%x", (unsigned long long)i, s->spheres[i].material_type);
+    const bool have_mesh = s->bvh_nodes && s->num_nodes > 0;
+    const bool many_meshes = have_mesh && s->meshes && s->num_meshes > 0;
+    if (have_mesh && !many_meshes && !known_type(s->mesh_material_type))
+        return fail(ctx, PT_ERR_ARG, "mesh: invalid material type 0x%x", s->mesh_material_type);
+    if (many_meshes) {
+        if (!s->bvh_prim_ids) return fail(ctx, PT_ERR_ARG, "several meshes need bvh_prim_ids");
+        if (s->num_meshes > 65536) return fail(ctx, PT_ERR_ARG, "more than 65536 meshes");
+        for (uint64_t k = 0; k < s->num_meshes; k++) {
+            if (!known_type(s->meshes[k].material_type))
+                return fail(ctx, PT_ERR_ARG, "mesh %llu: invalid material type 0x%x", (unsigned long long)k, s->meshes[k].material_type);
+            if (k == 0 ? s->meshes[0].first_face != 0 : s->meshes[k].first_face < s->meshes[k - 1].first_face)
+                return fail(ctx, PT_ERR_ARG, "mesh %llu: first_face out of order (the first mesh starts at face 0)", (unsigned long long)k);
+        }
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -1096,6 +1258,9 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             std::memcpy(&meta, m, 8);
             nohit[3] = meta;
         }
+        std::vector<uint32_t> mesh_first;
+        if (many_meshes)
+            for (uint64_t k = 0; k < s->num_meshes; k++) mesh_first.push_back(s->meshes[k].first_face);
         // where every inner node goes (see node_layout_pairs)
         std::vector<uint32_t> newid;
         if (ctx->node_layout == 1) {
@@ -1120,8 +1285,12 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                     for (uint64_t k = 0; k < count; k++, a += 3, out += 4) {
                         std::memcpy(out, tf + a * 4, 48);
                         float4 meta = make_float4(0, 0, 0, 0);
-                        const uint32_t m[2] = {s->bvh_prim_ids ? s->bvh_prim_ids[a] : (uint32_t)a, k + 1 == count ? 1u : 0u};
-                        std::memcpy(&meta, m, 8);
+                        const uint32_t prim = s->bvh_prim_ids ? s->bvh_prim_ids[a] : (uint32_t)a;
+                        uint32_t mesh = 0;
+                        if (many_meshes)        // last mesh whose first face is not beyond this one
+                            mesh = (uint32_t)(std::upper_bound(mesh_first.begin(), mesh_first.end(), prim) - mesh_first.begin()) - 1u;
+                        const uint32_t m[3] = {prim, k + 1 == count ? 1u : 0u, mesh};
+                        std::memcpy(&meta, m, 12);
                         out[3] = meta;
                     }
                     ch[c] = (int32_t)run_at[2 * i + c];
@@ -1154,8 +1323,23 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
         sc.first_tri = (uint32_t)N;
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
-        sc.mesh_type = s->mesh_material_type;
-        sc.mesh_mat = make_float4(s->mesh_material[0], s->mesh_material[1], s->mesh_material[2], s->mesh_material[3]);
+        if (many_meshes) {
+            std::vector<DMesh> dm(s->num_meshes);
+            for (uint64_t k = 0; k < s->num_meshes; k++) {
+                const pt_mesh &m = s->meshes[k];
+                dm[k].mat = make_float4(m.material[0], m.material[1], m.material[2], m.material[3]);
+                dm[k].type = m.material_type;
+            }
+            if ((rc = upload(ctx, dm, &sc.meshes)) != PT_OK) return rc;
+            sc.num_meshes = (uint32_t)s->num_meshes;
+            // one mesh in a list is the one-mesh case
+            sc.mesh_type = dm[0].type;
+            sc.mesh_mat = dm[0].mat;
+        } else {
+            sc.num_meshes = 1;
+            sc.mesh_type = s->mesh_material_type;
+            sc.mesh_mat = make_float4(s->mesh_material[0], s->mesh_material[1], s->mesh_material[2], s->mesh_material[3]);
+        }
     }
 
     // ---- analytic primitives ------------------------------------------------------------------------------------
@@ -1174,7 +1358,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
         spheres[i].mat = make_float4(p.material[0], p.material[1], p.material[2], p.material[3]);
         spheres[i].type = p.material_type;
     }
-    if (s->num_planes >= (1u << 30) || s->num_spheres >= (1u << 30)) return fail(ctx, PT_ERR_ARG, "too many primitives");
     int rc;
     if ((rc = upload(ctx, planes, &sc.planes)) != PT_OK) return rc;
     if ((rc = upload(ctx, spheres, &sc.spheres)) != PT_OK) return rc;
@@ -1464,13 +1647,16 @@ int pt_film_reduce(pt_ctx *const *ctxs, int n, int root)
     if (!ctxs || n < 1 || root < 0 || root >= n || !ctxs[root]) return PT_ERR_ARG;
     pt_ctx *dst = ctxs[root];
     if (!dst->film) return fail(dst, PT_ERR_STATE, "pt_film_reduce: no film bound");
+    bool distinct_devices = true;
     for (int i = 0; i < n; i++) {
         if (!ctxs[i] || !ctxs[i]->film) return fail(dst, PT_ERR_STATE, "pt_film_reduce: context %d has no film", i);
         if (ctxs[i]->W != dst->W || ctxs[i]->H != dst->H)
             return fail(dst, PT_ERR_ARG, "pt_film_reduce: context %d has a %ux%u film, the root %ux%u", i, ctxs[i]->W,
                         ctxs[i]->H, dst->W, dst->H);
-        for (int j = 0; j < i; j++)
+        for (int j = 0; j < i; j++) {
             if (ctxs[j] == ctxs[i]) return fail(dst, PT_ERR_ARG, "pt_film_reduce: context %d is listed twice", i);
+            if (ctxs[j]->device == ctxs[i]->device) distinct_devices = false;
+        }
     }
     const uint64_t count = (uint64_t)dst->W * dst->H * 3;
     // every film must be complete before it is read from another stream
@@ -1479,8 +1665,17 @@ int pt_film_reduce(pt_ctx *const *ctxs, int n, int root)
         HIPCHK(dst, hipStreamSynchronize(ctxs[i]->stream));
     }
     HIPCHK(dst, hipSetDevice(dst->device));
+    // PT_FILM_REDUCE_RCCL=1 sends even a single context through RCCL (a one-rank reduce, in place): a way to exercise
+    // the binding on a machine with one GPU
+    if (n == 1) {
+        const char *force = std::getenv("PT_FILM_REDUCE_RCCL");
+        if (!(force && force[0] == '1')) return PT_OK;
+    }
+    // One context per GPU: one RCCL reduce over xGMI.  (RCCL takes one rank per device, so contexts that share a device
+    // -- two contexts on one GPU, as the single-GPU tests use -- are summed by copies and adds on the root instead.)
+    if (distinct_devices) return film_reduce_rccl(ctxs, n, root, count);
     float *staging = nullptr;
-    if (n > 1) HIPCHK(dst, hipMalloc(&staging, count * sizeof(float)));
+    HIPCHK(dst, hipMalloc(&staging, count * sizeof(float)));
     hipError_t e = hipSuccess;
     for (int i = 0; i < n && e == hipSuccess; i++) {
         if (i == root) continue;
@@ -1516,7 +1711,18 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
     slab_samples = std::min<uint64_t>(slab_samples, std::max<uint64_t>(1, spp_count));
     if (ctx->slab_bytes < slab_samples * per_sample) {
         if (ctx->slab) { (void)hipFree(ctx->slab); ctx->slab = nullptr; ctx->slab_bytes = 0; }
-        HIPCHK(ctx, hipMalloc(&ctx->slab, slab_samples * per_sample));
+        // the budget is a wish: when the device cannot give that much (other users of its memory), halve the slab until
+        // it fits; the call then simply runs more slabs
+        for (;;) {
+            const hipError_t e = hipMalloc(&ctx->slab, slab_samples * per_sample);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            ctx->slab = nullptr;
+            if (e != hipErrorOutOfMemory || slab_samples == 1)
+                return fail(ctx, PT_ERR_HIP, "pt_render: sample slab of %llu bytes: %s",
+                            (unsigned long long)(slab_samples * per_sample), hipGetErrorString(e));
+            slab_samples = (slab_samples + 1) / 2;
+        }
         ctx->slab_bytes = slab_samples * per_sample;
     }
 
@@ -1536,7 +1742,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         for (int k = 0; k < nl; k++) {
             const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
             int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
-            if (rc != PT_OK) return rc;
+            if (rc != PT_OK) return drain_lanes(ctx, rc);
         }
         // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
         for (int live = nl; live > 0;) {
@@ -1544,7 +1750,7 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
                 Lane &ln = ctx->lanes[k];
                 if (ln.done) continue;
                 int rc = lane_iterate(ctx, ln, s0, s1);
-                if (rc != PT_OK) return rc;
+                if (rc != PT_OK) return drain_lanes(ctx, rc);
                 if (ln.done) live--;
             }
         }

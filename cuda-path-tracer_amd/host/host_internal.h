@@ -36,6 +36,7 @@ struct pth_scene {
     pth_bvh bvh{};
     std::vector<pt_plane> planes;
     std::vector<pt_sphere> spheres;
+    std::vector<pt_mesh> meshes;
     std::vector<float> env;
     std::vector<uint64_t> marginal, conditional;
 };

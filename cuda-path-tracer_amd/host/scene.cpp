@@ -76,8 +76,17 @@ int obj_load(const std::string &path, std::vector<float> &verts, uint64_t &ntris
         if (!eol) eol = end;
         while (p < eol && (*p == ' ' || *p == '\t')) p++;
         if (p < eol && p[0] == 'v' && p + 1 < eol && (p[1] == ' ' || p[1] == '\t')) {
+            // three coordinates, all on this line: strtof skips newlines, so a short record must not be allowed to take
+            // the next record's first number
             char *q = const_cast<char *>(p + 1);
-            for (int k = 0; k < 3; k++) pos.push_back(std::strtof(q, &q));
+            for (int k = 0; k < 3; k++) {
+                while (q < eol && (*q == ' ' || *q == '\t')) q++;
+                char *e = q;
+                const float c = q < eol ? std::strtof(q, &e) : 0.0f;
+                if (e == q || e > eol) return set_error("%s: vertex record with fewer than 3 coordinates", path.c_str());
+                pos.push_back(c);
+                q = e;
+            }
         } else if (p < eol && p[0] == 'f' && p + 1 < eol && (p[1] == ' ' || p[1] == '\t')) {
             char *q = const_cast<char *>(p + 1);
             long idx[3];
@@ -207,7 +216,8 @@ int pth_scene_load(const char *scene_file, uint32_t width, uint32_t height, pth_
     if (!in) return set_error("cannot open %s", scene_file);
     const std::vector<Block> blocks = read_blocks(in);
     pth_scene *sc = new pth_scene();
-    bool have_camera = false, have_env = false, have_obj = false;
+    bool have_camera = false, have_env = false;
+    std::vector<float> all_verts;           // triangles of all OBJ blocks, in block order
     int rc = 0;
     for (const Block &b : blocks) {
         if (b.kind == "CAMERA") {
@@ -254,8 +264,10 @@ int pth_scene_load(const char *scene_file, uint32_t width, uint32_t height, pth_
             p.normal[0] = n[0] * s; p.normal[1] = n[1] * s; p.normal[2] = n[2] * s;
             sc->planes.push_back(p);
         } else if (b.kind == "OBJ") {
-            if (have_obj) { rc = set_error("only one obj allowed per scene"); break; }
-            if ((rc = read_material(b, sc->desc.mesh_material, sc->desc.mesh_material_type)) != 0) break;
+            // The reference allows one OBJ block (src/scene.cu:187-188).  Several are accepted here: their triangles go
+            // into ONE BVH in block order, each mesh keeping its own material.
+            pt_mesh m{};
+            if ((rc = read_material(b, m.material, m.material_type)) != 0) break;
             std::string name;
             if (!get_string(b, "file_name", name)) { rc = set_error("OBJ without file_name"); break; }
             std::vector<float> verts;
@@ -263,11 +275,20 @@ int pth_scene_load(const char *scene_file, uint32_t width, uint32_t height, pth_
             std::cout << "Loading .obj file...\n";
             if ((rc = obj_load(resolve(name, scene_file), verts, ntris)) != 0) break;
             std::cout << "Loaded " << ntris << " triangles\n";
-            std::cout << "Constructing BVH...\n";
-            const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-            if ((rc = bvh_build(verts.data(), ntris, threads, &sc->bvh)) != 0) break;
-            have_obj = true;
+            if (all_verts.size() / 9 + ntris >= 0x40000000ull) { rc = set_error("more than 2^30 triangles"); break; }
+            m.first_face = (uint32_t)(all_verts.size() / 9);
+            if (sc->meshes.empty()) all_verts.swap(verts);
+            else all_verts.insert(all_verts.end(), verts.begin(), verts.end());
+            sc->meshes.push_back(m);
         }
+    }
+    if (rc == 0 && !sc->meshes.empty()) {
+        std::cout << "Constructing BVH...\n";
+        const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        rc = bvh_build(all_verts.data(), all_verts.size() / 9, threads, &sc->bvh);
+        // the first mesh's material doubles as the scene's single mesh material, which is all a one-OBJ scene needs
+        std::memcpy(sc->desc.mesh_material, sc->meshes[0].material, sizeof sc->desc.mesh_material);
+        sc->desc.mesh_material_type = sc->meshes[0].material_type;
     }
     if (rc == 0 && !have_camera) rc = set_error("%s: no CAMERA block", scene_file);
     if (rc == 0 && !have_env) rc = set_error("%s: no ENVIRONMENT block", scene_file);
@@ -284,6 +305,7 @@ int pth_scene_load(const char *scene_file, uint32_t width, uint32_t height, pth_
     d.env_texels = sc->env.data();
     d.env_marginal = sc->marginal.data();
     d.env_conditional = sc->conditional.data();
+    if (sc->meshes.size() > 1) { d.meshes = sc->meshes.data(); d.num_meshes = sc->meshes.size(); }
     *out = sc;
     return 0;
 }

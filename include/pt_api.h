@@ -61,6 +61,13 @@ typedef struct {                /* reference src/camera.cuh:14-18 (class Camera,
     float lens_radius;
 } pt_camera;
 
+typedef struct {                /* one OBJ block of a .scene file.  The reference allows a single one per scene (src/scene.cu:
+                                   186-200, one material per BVH: src/bvh.cuh:64-65); several are a superset of it. */
+    float material[4];
+    uint32_t material_type;
+    uint32_t first_face;        /* bvh_prim_ids value of the mesh's first triangle; meshes are listed in ascending order */
+} pt_mesh;
+
 /*
  * Host-side description of a scene: exactly the buffers the reference's Scene constructor uploads
  * (src/scene.cu:138-221), as host pointers.
@@ -73,6 +80,10 @@ typedef struct {                /* reference src/camera.cuh:14-18 (class Camera,
  *                    (src/environment_map.cu:88-104,142-147)
  *   env_marginal     size_t[env_width]; env_conditional size_t[env_width*env_height], index x*height+y
  *                    (src/environment_map.cu:107-134)
+ *   meshes           pt_mesh[num_meshes] or NULL.  NULL / 0: every triangle has mesh_material / mesh_material_type (the
+ *                    reference's case).  Otherwise ONE BVH over the triangles of all meshes; a triangle with prim id p has
+ *                    the material of the last mesh whose first_face <= p (meshes[0].first_face must be 0), and
+ *                    mesh_material / mesh_material_type are ignored.  Needs bvh_prim_ids.
  * A scene without a mesh passes bvh_nodes = NULL, num_nodes = 0.
  */
 typedef struct {
@@ -95,6 +106,8 @@ typedef struct {
     const float *env_texels;
     const uint64_t *env_marginal;
     const uint64_t *env_conditional;
+    const pt_mesh *meshes;
+    uint64_t num_meshes;
 } pt_scene_desc;
 
 typedef struct {
@@ -186,11 +199,15 @@ int  pt_film_download(pt_ctx *ctx, float *rgb_out);    /* replaces the cudaMemcp
  * pth_tonemap16's by one step of 65535. */
 int  pt_film_tonemap16(pt_ctx *ctx, float exposure, float gamma, uint16_t *rgb_out);
 
-/* Film reduce for a process that drives several GPUs: adds the films of the other contexts to the film of
- * ctxs[root], in index order (peer copies over xGMI + adds on the root's device), and returns when the sum is complete.
- * All films must have the root's size; the other films are left as they are.  Contexts on the same device work too.
+/* Film reduce for a process that drives several GPUs: adds the films of the other contexts to the film of ctxs[root] and
+ * returns when the sum is complete.  Contexts on distinct GPUs: ONE RCCL reduce (ncclReduce, sum, float32, width*height*3
+ * elements) over xGMI, every rank on its context's stream; librccl is bound at the first such call, not linked, and the
+ * communicators are kept until the last context of the process is destroyed.  Contexts that share a GPU (RCCL takes one
+ * rank per device): copies into a staging buffer on the root's device and adds, in index order.  All films must have the
+ * root's size; the other films are left as they are.  The sum equals the sum of the films up to float addition order.
  * No reference counterpart (the reference renders on one GPU).  With one process per GPU the same reduce is one
- * RCCL call on the bound film buffers instead (see pt_film_bind). */
+ * RCCL call on the bound film buffers instead (see pt_film_bind).  PT_FILM_REDUCE_RCCL=1 in the environment sends a
+ * single context through RCCL too (a one-rank reduce that changes nothing), to check the binding on a one-GPU machine. */
 int  pt_film_reduce(pt_ctx *const *ctxs, int n, int root);
 
 /* Replaces render_scene (reference src/render.cuh:50, src/render.cu:244-280): accumulates samples

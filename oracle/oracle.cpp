@@ -204,7 +204,15 @@ inline void hit_triangle(const float *v00, const float *v11, const float *v22, V
             if (v >= 0.0f && u + v <= 1.0f) {
                 h.t = t;
                 h.n = cross3(ld3(v11), ld3(v22));
-                h.mat = sc->mesh_material; h.mat_type = sc->mesh_material_type; h.prim = prim;
+                h.prim = prim;
+                if (sc->meshes && sc->num_meshes > 0) {
+                    // several OBJ blocks: the material of the mesh this face belongs to
+                    uint64_t k = sc->num_meshes - 1;
+                    while (k > 0 && sc->meshes[k].first_face > prim) k--;
+                    h.mat = sc->meshes[k].material; h.mat_type = sc->meshes[k].material_type;
+                } else {
+                    h.mat = sc->mesh_material; h.mat_type = sc->mesh_material_type;
+                }
             }
         }
     }

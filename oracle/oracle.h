@@ -68,6 +68,12 @@ typedef struct {            /* reference src/camera.cuh:14-18 */
     float lens_radius;
 } orc_camera;
 
+typedef struct {            /* one OBJ block; a superset of the reference's single mesh (src/scene.cu:186-200) */
+    float material[4];
+    uint32_t material_type;
+    uint32_t first_face;    /* prim id of the mesh's first triangle, ascending over the array */
+} orc_mesh;
+
 typedef struct {
     const float *bvh_nodes;          /* 16 floats per node, reference src/bvh.cu:36-41 */
     uint64_t num_nodes;
@@ -88,6 +94,8 @@ typedef struct {
     const float *env_texels;         /* float4 [height][width], row 0 = top, .w = solid-angle pdf */
     const uint64_t *env_marginal;    /* [width] */
     const uint64_t *env_conditional; /* [width*height], index x*height + y, y = 0 is the bottom row */
+    const orc_mesh *meshes;          /* NULL: one mesh with mesh_material; else a triangle with prim id p has the material */
+    uint64_t num_meshes;             /* of the last mesh whose first_face <= p */
 } orc_scene_desc;
 
 typedef struct {

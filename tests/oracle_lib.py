@@ -31,6 +31,10 @@ class Camera(C.Structure):
                 ("lens_radius", C.c_float)]
 
 
+class Mesh(C.Structure):
+    _fields_ = [("material", C.c_float * 4), ("material_type", C.c_uint32), ("first_face", C.c_uint32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("bvh_nodes", C.c_void_p), ("num_nodes", C.c_uint64),
                 ("bvh_tris", C.c_void_p), ("num_tri_float4", C.c_uint64),
@@ -40,7 +44,8 @@ class SceneDesc(C.Structure):
                 ("spheres", C.c_void_p), ("num_spheres", C.c_uint64),
                 ("camera", Camera),
                 ("env_width", C.c_uint32), ("env_height", C.c_uint32),
-                ("env_texels", C.c_void_p), ("env_marginal", C.c_void_p), ("env_conditional", C.c_void_p)]
+                ("env_texels", C.c_void_p), ("env_marginal", C.c_void_p), ("env_conditional", C.c_void_p),
+                ("meshes", C.c_void_p), ("num_meshes", C.c_uint64)]
 
 
 class Bvh(C.Structure):

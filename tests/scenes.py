@@ -180,8 +180,44 @@ file_name {city}
 """,
 }
 
+# two OBJ blocks with different materials (a superset of the reference's one-OBJ scenes): the shipped low-poly bunny,
+# Lambertian, and the shipped suzanne moved to its side, glass
+SCENE_TEXT["two_meshes"] = """CAMERA
+position 0.5 1.6 5.5
+look_at 0.8 0.9 0
+fov 35
+aperture 0.02
+focus_dist 5.5
+
+ENVIRONMENT
+file_name {studio}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.3 0.3 0.35
+position 0 0 0
+normal 0 1 0
+
+OBJ
+material_type LAMBERTIAN
+albedo 0.6 0.3 0.1
+file_name {bunny_lowpoly}
+
+OBJ
+material_type GLASS
+albedo 0.9 1 0.9
+refraction_index 1.45
+file_name {suzanne_moved}
+
+SPHERE
+material_type MIRROR
+albedo 0.6 0.6 0.6
+position -1.6 0.5 0.3
+radius 0.5
+"""
+
 _SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"],
-                 "city": ["studio.hdr"]}
+                 "city": ["studio.hdr"], "two_meshes": ["studio.hdr"]}
 
 
 def scene_file(pkg, name):
@@ -191,6 +227,13 @@ def scene_file(pkg, name):
         paths[kind.split(".")[0]] = ensure_asset(pkg, kind)
     if name in ("bunny", "city"):
         paths[name] = ensure_mesh_obj(name)
+    if name == "two_meshes":
+        paths["bunny_lowpoly"] = ensure_mesh_obj("bunny_lowpoly")
+        paths["suzanne_moved"] = os.path.join(asset_dir(), "suzanne_moved.obj")
+        if not os.path.exists(paths["suzanne_moved"]):
+            tmp = paths["suzanne_moved"] + ".tmp%d" % os.getpid()
+            write_obj(tmp, two_meshes_triangles()[1])
+            os.replace(tmp, tmp[:tmp.index(".tmp")])
     path = os.path.join(asset_dir(), name + ".scene")
     text = SCENE_TEXT[name].format(**paths)
     if not os.path.exists(path) or open(path).read() != text:
@@ -199,6 +242,13 @@ def scene_file(pkg, name):
             fh.write(text)
         os.replace(tmp, path)
     return path
+
+
+def two_meshes_triangles():
+    """The triangles of the two_meshes scene's OBJ blocks, in block order."""
+    a = golden_mesh("bunny_lowpoly")
+    b = (golden_mesh("suzanne") * np.float32(0.8) + np.array([1.9, 0.9, 0.2], dtype=np.float32)).astype(np.float32)
+    return a, b
 
 
 def small_env(pkg, width=64, height=32):

@@ -420,3 +420,40 @@ def test_pfm_writer_keeps_the_exact_floats(pkg, tmp_path):
     assert raw.startswith(header)
     back = np.frombuffer(raw[len(header):], dtype="<f4").reshape(7, 5, 3)[::-1]
     assert np.array_equal(back, film)
+
+
+def test_scene_with_two_obj_blocks(pkg, tmp_path):
+    """Several OBJ blocks (the reference stops at one, src/scene.cu:187-188): one BVH over all triangles in block order,
+    a material per mesh; a one-OBJ scene still describes itself exactly as before."""
+    scene = pkg.HostScene(S.scene_file(pkg, "two_meshes"), 64, 48)
+    d = scene.desc
+    a, b = S.two_meshes_triangles()
+    assert d.num_meshes == 2 and d.num_tris == a.shape[0] + b.shape[0] == 316 + 968
+    meshes = C.cast(d.meshes, C.POINTER(pkg.Mesh * 2)).contents
+    assert (meshes[0].first_face, meshes[1].first_face) == (0, 316)
+    assert (meshes[0].material_type, meshes[1].material_type) == (pkg.DIFFUSE, pkg.GLASS)
+    assert abs(meshes[1].material[3] - 1.45) < 1e-6
+    # the BVH is the BVH of the concatenated triangles
+    whole = pkg.bvh_build(np.concatenate([a, b]))
+    nodes = np.ctypeslib.as_array(C.cast(d.bvh_nodes, C.POINTER(C.c_float)), shape=(d.num_nodes, 16))
+    ids = np.ctypeslib.as_array(C.cast(d.bvh_prim_ids, C.POINTER(C.c_uint32)), shape=(d.num_tri_float4,))
+    assert np.array_equal(nodes.view(np.uint32), whole["nodes"].view(np.uint32))
+    assert np.array_equal(ids, whole["prim_ids"])
+    # a ray at the second mesh reports a face of the second mesh
+    org = np.array([[1.9, 0.9, 6.0]], np.float32)
+    dir_ = np.array([[0.013, 0.021, -1.0]], np.float32)
+    dir_ /= np.linalg.norm(dir_)
+    t, prim, _, _ = O.intersect(S.as_oracle_desc(scene), org, dir_)
+    assert 316 <= prim[0] < 316 + 968
+    one = pkg.HostScene(S.scene_file(pkg, "city"), 64, 48)
+    assert one.desc.num_meshes == 0 and not one.desc.meshes
+
+
+def test_obj_vertex_record_must_hold_three_coordinates(pkg, tmp_path):
+    """A short `v x y` record is an error, not a silent shift of every later coordinate."""
+    path = tmp_path / "short.obj"
+    path.write_text("v 0 0 0\nv 1 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\n")
+    with pytest.raises(pkg.PtError, match="fewer than 3"):
+        pkg.obj_load(str(path))
+    path.write_text("v 0 0 0\nv 1 0 0   \nv 0 1 0\r\nf 1 2 3\n")
+    assert pkg.obj_load(str(path)).shape == (1, 3, 3)

@@ -3,6 +3,7 @@
 Bars: primitive ids bit-exact; hit distance t within 1e-5 relative (the tests in fact demand bit equality, which the
 fixed fma sequence delivers); camera rays bit-exact; films within the tolerances stated at each test.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -222,6 +223,48 @@ def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
+def test_scene_with_two_meshes_matches_oracle(pkg, ctx):
+    """Two OBJ blocks with different materials (Lambertian bunny, glass suzanne) in one BVH: hits bit-equal to the oracle,
+    the film inside the usual bars, and the per-mesh material visibly in effect (the same triangles with one material
+    for all give another film)."""
+    W, H, spp = 96, 64, 8
+    scene = pkg.HostScene(S.scene_file(pkg, "two_meshes"), W, H)
+    assert scene.desc.num_meshes == 2
+    ctx.upload(scene)
+    org, dir_ = S.ray_batch(scene, W, H, seed=15)
+    t, prim, nrm = ctx.intersect(org, dir_, want_normals=True)
+    ot, oprim, onrm, _ = O.intersect(S.as_oracle_desc(scene), org, dir_, want_normals=True)
+    check_hits(t, prim, ot, oprim, "two meshes")
+    assert np.array_equal(t, ot)
+    assert ((prim < 316)).any() and ((prim >= 316) & (prim < 316 + 968)).any()
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=5)
+    film = ctx.film_download()
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
+    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
+    rel_mse, differing = film_metrics(film, ofilm)
+    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
+    floor, _ = film_metrics(ofilm2, ofilm)
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
+    # the same buffers as ONE mesh (the first material for every triangle): a different image
+    one = pkg.SceneDesc.from_buffer_copy(scene.desc)
+    one.meshes, one.num_meshes = None, 0
+    ctx.upload(one)
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=5)
+    assert film_metrics(ctx.film_download(), film)[1] > 0.02
+    # a mesh list that does not start at face 0, or names an unknown material, is refused
+    bad = (pkg.Mesh * 2)(pkg.Mesh((C.c_float * 4)(1, 1, 1, 0), pkg.DIFFUSE, 5), pkg.Mesh((C.c_float * 4)(1, 1, 1, 0), pkg.GLASS, 316))
+    d2 = pkg.SceneDesc.from_buffer_copy(scene.desc)
+    d2.meshes, d2.num_meshes = C.addressof(bad), 2
+    with pytest.raises(pkg.PtError, match="first_face"):
+        ctx.upload(d2)
+    bad[0].first_face, bad[1].material_type = 0, 3
+    with pytest.raises(pkg.PtError, match="invalid material"):
+        ctx.upload(d2)
+
+
 def test_render_matches_frozen_film(pkg, ctx):
     """Same bar as above against the film frozen in tests/golden/film_knot.npz (no oracle run involved)."""
     g = np.load(os.path.join(GOLDEN, "film_knot.npz"))
@@ -307,6 +350,23 @@ def test_film_reduce_across_contexts(pkg, ctx):
             pkg.film_reduce([ctx, other])
     finally:
         other.close()
+
+
+def test_film_reduce_binds_rccl(pkg, ctx, monkeypatch):
+    """Contexts on distinct GPUs are summed by one ncclReduce; this box has one GPU, so the binding (library lookup, symbols,
+    communicator, the call on the context's stream) is exercised with a one-rank reduce, which must leave the film as is."""
+    W, H, spp = 96, 64, 2
+    ctx.upload(S.knot_scene(pkg, W, H))
+    ctx.film_bind(W, H)
+    ctx.render(0, spp, spp, seed=6)
+    before = ctx.film_download()
+    monkeypatch.setenv("PT_FILM_REDUCE_RCCL", "1")
+    pkg.film_reduce([ctx], root=0)
+    pkg.film_reduce([ctx], root=0)              # the communicator is reused
+    assert np.array_equal(ctx.film_download(), before)
+    monkeypatch.delenv("PT_FILM_REDUCE_RCCL")
+    pkg.film_reduce([ctx], root=0)
+    assert np.array_equal(ctx.film_download(), before)
 
 
 def test_command_line_matches_library(pkg, ctx, tmp_path):
@@ -522,6 +582,15 @@ def test_error_paths(pkg):
         c.set_option(pkg.OPT_POOL_SIZE, 8)
     with pytest.raises(pkg.PtError):
         pkg.Context(99)
+    # a scene that is refused leaves the uploaded one in place: unknown material type, a count without its array
+    bad = S.spheres_scene(pkg, 48, 32)
+    C.cast(bad.desc.spheres, C.POINTER(pkg.Sphere))[1].material_type = 0x40
+    with pytest.raises(pkg.PtError, match="invalid material type"):
+        c.upload(bad)
+    d = pkg.SceneDesc.from_buffer_copy(scene.desc)
+    d.planes = None
+    with pytest.raises(pkg.PtError, match="without primitive array"):
+        c.upload(d)
     # an empty sample range is a no-op; a single sample uses one stream
     st = c.render(2, 0, 4)
     assert st.paths == 0 and st.rays == 0 and not c.film_download().any()
