@@ -20,6 +20,7 @@ OPT_ENV_PACK = 8
 OPT_STREAMS = 9
 OPT_TUNE_EXTEND_BLOCKS = 10
 OPT_NODE_LAYOUT = 11
+OPT_TUNE_XCD_GROUP = 12
 
 
 class Plane(C.Structure):

@@ -46,6 +46,7 @@ struct ExtendArgs {
     int refill_idle;
     int lds_slots;             // traversal stack slots per lane kept in LDS
     int *gstk;                 // stack slots beyond lds_slots: [slot - lds_slots][global thread]  (OVERFLOW only)
+    int xcd_group;             // stream kernel: 1 = the blocks of an XCD share one contiguous eighth of the ray buffer
 };
 
 // Per-lane traversal state.  The hit is kept as (t, hid): hid = PT_PRIM_PLANE|i, PT_PRIM_SPHERE|i, the record index of
@@ -304,11 +305,23 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
 {
     const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
-    const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
-    // wave-uniform cursor over this wave's chunks of the ray buffer
+    // wave-uniform cursor over this wave's chunks of the ray buffer: chunks first, first + step, ... below last
     uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
-    uint32_t next = chunk * kChunk;
-    uint32_t end = next < n ? min(n, next + kChunk) : next;
+    uint32_t chunk_step = (gridDim.x * kBlock) >> 6;
+    uint32_t chunk_last = (uint32_t)(((uint64_t)n + kChunk - 1) / kChunk);
+    if (a.xcd_group && (gridDim.x & 7u) == 0) {
+        // Blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8 share an L2.  Give each XCD one contiguous
+        // eighth of the buffer: rays that are neighbours in the buffer start close together in space, and an L2 then
+        // holds the subtrees around its own eighth instead of a share of all of them.  (Speed only: nothing depends on
+        // where a block really runs.)
+        const uint32_t xcd = blockIdx.x & 7u;
+        const uint32_t first = (uint32_t)((uint64_t)chunk_last * xcd / 8), last = (uint32_t)((uint64_t)chunk_last * (xcd + 1) / 8);
+        chunk_step = (gridDim.x >> 3) * (kBlock >> 6);
+        chunk = first + __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) * (kBlock >> 6) + (threadIdx.x >> 6));
+        chunk_last = last;
+    }
+    uint32_t next = chunk < chunk_last ? chunk * kChunk : 0;
+    uint32_t end = chunk < chunk_last ? min(n, next + kChunk) : next;
 
     RayState R;
     R.c_nodes = R.c_tris = R.c_leaves = 0;
@@ -334,8 +347,8 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             const bool empty = ray == kNoRay;
             const unsigned long long emask = __ballot(empty);
             if (next >= end) {
-                const uint64_t c2 = (uint64_t)chunk + nwaves;
-                if (c2 * kChunk < n) {
+                const uint64_t c2 = (uint64_t)chunk + chunk_step;
+                if (c2 < chunk_last) {
                     chunk = (uint32_t)c2;
                     next = chunk * kChunk;
                     end = min(n, next + kChunk);
@@ -350,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
                 degenerate = slab_degenerate(R.d);
             }
             next += take;
-            more_work = next < end || ((uint64_t)chunk + nwaves) * kChunk < n;
+            more_work = next < end || (uint64_t)chunk + chunk_step < chunk_last;
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }

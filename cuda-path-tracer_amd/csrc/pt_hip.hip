@@ -110,18 +110,19 @@ __device__ __forceinline__ float4 escape_value(float4 th, float4 e)
 }
 
 // --------------------------------------------------------------------------------------------------------------
-// shade: reference src/render.cu:129-242.  Returns the new direction and scales the throughput.  env_out = environment
-// texel in the new direction (the Lambertian pdf needs it, the caller stores the path's escape value from it).
+// shade: reference src/render.cu:129-242.  Returns the new direction and scales the throughput, all but the Lambertian
+// mixture weight: that needs the environment texel in the new direction, which the caller looks up (it stores the path's
+// escape value from the same texel) and hands to lambert_weight.
 // One body for all four materials, chosen per lane by `slot` (0 Lambertian, 1 glossy, 2 mirror, 3 glass): the lanes of a
 // wave hit different materials, and with a body per material the wave ran the Lambertian sampling and the environment
 // lookup once for each material present.  Each lane still draws its random numbers in the order its material's
 // reference kernel does.
 // --------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f3 shade_dir(const DScene &sc, int slot, f3 d, f3 n3, float4 mat, Rng &rng, float4 &th,
-                                        float4 &env_out)
+                                        bool &lambert)
 {
     f3 out = mk3(0, 0, 0);
-    bool lambert = slot == 0;                           // Lambertian (src/render.cu:129-162)
+    lambert = slot == 0;                                // Lambertian (src/render.cu:129-162)
     bool mirror = slot == 2;                            // mirror (src/render.cu:195-211)
     f3 nn = n3;                                         // the normal a reflection uses
     if (slot == 3) {                                    // glass (src/render.cu:213-242)
@@ -139,15 +140,18 @@ __device__ __forceinline__ f3 shade_dir(const DScene &sc, int slot, f3 d, f3 n3,
     if (mirror) out = reflect3(d, nn);
     if (slot >= 2) { th.x *= mat.x; th.y *= mat.y; th.z *= mat.z; }
     if (lambert) out = (rng.next() < 0.5f) ? diffuse_dir(n3, rng) : env_sample_lights(sc, rng);
-    env_out = env_lookup(sc, out);
-    if (lambert) {
-        const float env_pdf = env_out.w;
-        const float diff_pdf = fmaxf(dot3(n3, out) / kPi, 0.0f);
-        const float mixed_pdf = (env_pdf + diff_pdf) * 0.5f;
-        const float s = diff_pdf / mixed_pdf;
-        th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
-    }
     return out;
+}
+
+// second half of the Lambertian case (reference src/render.cu:145-151): the one-sample mixture weight, from the
+// environment texel in the new direction
+__device__ __forceinline__ void lambert_weight(f3 n3, f3 out, float4 mat, float4 env_out, float4 &th)
+{
+    const float env_pdf = env_out.w;
+    const float diff_pdf = fmaxf(dot3(n3, out) / kPi, 0.0f);
+    const float mixed_pdf = (env_pdf + diff_pdf) * 0.5f;
+    const float s = diff_pdf / mixed_pdf;
+    th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -272,7 +276,9 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
         const uint32_t sk = __float_as_uint(th.w);
         const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
         const uint32_t pixel = __float_as_uint(d4.w);
-        // a miss or the depth limit ends the path with the escape value its slab entry already holds
+        // A miss or the depth limit ends the path with the escape value its slab entry already holds -- except a camera ray
+        // that went through the tree and missed: the generate kernel leaves that entry to be written here.
+        const bool late_miss = i < n && t == kFltMax && k == 0;
         if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
             alive = true;
             if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
@@ -291,19 +297,27 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
         int cls = RAY_DROP;
         float nt = kFltMax;
         uint32_t nhid = PT_PRIM_MISS;
+        f3 n3 = out;
+        float4 mat = make_float4(0, 0, 0, 0);
+        bool lambert = false;
         if (alive) {
-            float4 mat;
             uint32_t mat_type;
             material_of(sc, hid, mat, mat_type);
             const int slot = mat_slot(mat_type);
             const f3 o = xyz(o4), d = xyz(d4);
             uint32_t prim;
-            const f3 n3 = hit_normal(sc, hid, o, d, t, prim);
+            n3 = hit_normal(sc, hid, o, d, t, prim);
             hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
             Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
-            float4 e;
-            out = shade_dir(sc, slot, d, n3, mat, rng, th, e);
+            out = shade_dir(sc, slot, d, n3, mat, rng, th, lambert);
+        }
+        if (alive || late_miss) {
+            // one environment lookup serves both: the new ray's direction, or the direction of the camera ray that missed
+            const float4 e = env_lookup(sc, alive ? out : xyz(d4));
+            if (lambert) lambert_weight(n3, out, mat, e, th);
             st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
+        }
+        if (alive) {
             th.w = __uint_as_float(sample | ((k + 1) << 27));
             // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
             // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
@@ -346,8 +360,8 @@ __global__ void k_take(Counters *cnt, uint32_t P)
 #endif
 constexpr int kGenBlock = PT_GENBLOCK;
 __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t P, uint32_t W,
-                                                     uint32_t H, uint32_t spp_begin, uint32_t seed0, uint32_t seed1,
-                                                     float4 *__restrict__ slab)
+                                                     uint32_t H, FastDiv row_div, uint32_t spp_begin, uint32_t seed0,
+                                                     uint32_t seed1, float4 *__restrict__ slab)
 {
     __shared__ uint32_t s_wave[2][kGenBlock / 64];
     __shared__ unsigned long long s_base[2];
@@ -356,6 +370,16 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
     const unsigned long long first = cnt->gen_first;
     const uint32_t npix = W * H;
     const uint32_t stride = gridDim.x * kGenBlock;
+    // Path j of this launch is global sample index g = first + j = s_local * npix + r (sample-major: all pixels of a sample,
+    // then the next sample).  The division is done once per thread; from one trip of the loop to the next g grows by the
+    // stride, so (s_local, r) follow by an addition and at most a carry.
+    uint32_t s_local, r;
+    {
+        const unsigned long long g0 = first + blockIdx.x * kGenBlock + threadIdx.x;
+        s_local = (uint32_t)udiv_wide(g0, npix);
+        r = (uint32_t)(g0 - (unsigned long long)s_local * npix);
+    }
+    const uint32_t stride_s = udiv_small(stride, npix), stride_r = stride - stride_s * npix;
     int par = 0;
     for (uint32_t base = blockIdx.x * kGenBlock; base < take; base += stride, par ^= 1) {
         const uint32_t j = base + threadIdx.x;
@@ -366,21 +390,22 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
         float4 th = make_float4(0, 0, 0, 0);
         uint32_t pixel = 0;
         if (j < take) {
-            const unsigned long long g = first + j;
-            const uint32_t s_local = (uint32_t)udiv_wide(g, npix);
-            const uint32_t r = (uint32_t)(g - (unsigned long long)s_local * npix);
             const uint32_t sample = spp_begin + s_local;
             uint32_t x, y;
-            pixel_of(r, W, H, x, y);
+            pixel_of(r, W, H, row_div, x, y);
             pixel = (H - y - 1) * W + x;
             Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
             camera_ray(sc.cam, W, H, x, y, rng, o, d);
             th = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(sample));
-            st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
             // a camera ray into the sky completes its path here; one that hits a plane or sphere in front of the mesh
             // gets its hit stored now
             const bool settled = ray_settled_at_root(sc, o, d, nt, nhid);
             cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+            // The path's slab entry is only needed now if the path ends now.  A camera ray that hits something has its entry
+            // written when it is shaded (the first hit is never cut by depth or roulette), and one that goes through the
+            // tree and misses has it written by the bounce kernel when it finds the miss: waves whose pixels all show
+            // geometry skip the environment lookup (two inverse trigonometric functions and four texels) altogether.
+            if (cls == RAY_ESCAPED) st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
         }
         const uint32_t dst = block_append<kGenBlock>(cls, cnt, P, s_wave, s_base, par, escaped);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
@@ -392,6 +417,9 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
                 st_stream(B.t + dst, nt);
             }
         }
+        r += stride_r;
+        s_local += stride_s;
+        if (r >= npix) { r -= npix; s_local++; }
     }
     flush_escaped(cnt, escaped);
 }
@@ -467,13 +495,14 @@ __global__ __launch_bounds__(kBlock) void k_tonemap16(const float *__restrict__ 
 }
 
 // camera rays of one sample index in film-pixel order (parity check of the generate stage)
-__global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, uint32_t sample, uint32_t seed0,
-                                                    uint32_t seed1, float4 *__restrict__ ro, float4 *__restrict__ rd)
+__global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint32_t H, FastDiv row_div, uint32_t sample,
+                                                    uint32_t seed0, uint32_t seed1, float4 *__restrict__ ro,
+                                                    float4 *__restrict__ rd)
 {
     const uint32_t npix = W * H;
     for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < npix; r += gridDim.x * kBlock) {
         uint32_t x, y;
-        pixel_of(r, W, H, x, y);
+        pixel_of(r, W, H, row_div, x, y);
         const uint32_t pixel = (H - y - 1) * W + x;
         Rng rng(pixel, sample, 0, STAGE_CAMERA, seed0, seed1);
         f3 o, d;
@@ -565,6 +594,7 @@ struct pt_ctx {
     int lds_slots = 26;
     int extend_blocks = 8;     // cap on extend blocks per CU (the LDS stacks usually allow fewer)
     bool env_pack = true;      // use the packed environment texels when they are exact
+    int xcd_group = 0;         // extend: each XCD's blocks work on one contiguous eighth of the ray buffer
     int node_layout = 1;       // 0: inner nodes in the order given, 1: parent + favoured child share a 128 B line
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -762,6 +792,7 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
     a.refill_idle = ctx->refill_idle;
     a.lds_slots = lds_slots;
     a.gstk = gstk ? *gstk : nullptr;
+    a.xcd_group = ctx->xcd_group;
     const size_t shmem = (size_t)lds_slots * kBlock * sizeof(int);
     const bool count = ctx->count_traversal;
     const dim3 g(grid), b(kBlock);
@@ -820,8 +851,8 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
     const int gg = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kGenBlock),
                                                                  ((uint64_t)P + kGenBlock - 1) / kGenBlock));
-    hipLaunchKernelGGL(k_generate, dim3(gg), dim3(kGenBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H, (uint32_t)ln.first, s0, s1,
-                       ln.slab);
+    hipLaunchKernelGGL(k_generate, dim3(gg), dim3(kGenBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H,
+                       make_fastdiv(pixel_divisor(W, H)), (uint32_t)ln.first, s0, s1, ln.slab);
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, ls, ln.cnt, (ctx->count_traversal && ctx->sc.has_bvh) ? 1u : 0u,
                        ln.d_done);
     HIPCHK(ctx, hipGetLastError());         // of the four launches above
@@ -1161,6 +1192,7 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         ctx->extend_blocks = (int)value;
         return PT_OK;
     case PT_OPT_ENV_PACK: ctx->env_pack = value != 0; return PT_OK;
+    case PT_OPT_TUNE_XCD_GROUP: ctx->xcd_group = value != 0; return PT_OK;
     case PT_OPT_NODE_LAYOUT:
         if (value > 1) return fail(ctx, PT_ERR_ARG, "node layout %llu unknown", (unsigned long long)value);
         ctx->node_layout = (int)value;
@@ -1566,7 +1598,7 @@ int pt_primary_rays(pt_ctx *ctx, uint32_t W, uint32_t H, uint64_t sample, uint64
     hipError_t e = hipMalloc(&d_d, n * sizeof(float4));
     if (e != hipSuccess) { (void)hipFree(d_o); return fail(ctx, PT_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     hipLaunchKernelGGL(k_primary, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, ctx->sc, W, H,
-                       (uint32_t)sample, (uint32_t)seed, (uint32_t)(seed >> 32), d_o, d_d);
+                       make_fastdiv(pixel_divisor(W, H)), (uint32_t)sample, (uint32_t)seed, (uint32_t)(seed >> 32), d_o, d_d);
     std::vector<float4> ho(n), hd(n);
     e = hipMemcpyAsync(ho.data(), d_o, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hd.data(), d_d, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream);

@@ -144,6 +144,8 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_ENV_PACK         8   /* 1 (default): keep environment texels as shared-exponent word + pdf (8 B, tiled)
                                        when that reproduces every texel exactly; 0: always 16 B float texels.
                                        Read by pt_scene_upload. */
+#define PT_OPT_TUNE_XCD_GROUP   12  /* extend tuning: 1 = the blocks that share an XCD (and its L2) work on one contiguous eighth
+                                       of the ray buffer instead of chunks from all over it (default 0) */
 #define PT_OPT_NODE_LAYOUT      11  /* 1 (default): inner nodes are re-ordered at upload so that a node and the child a ray most
                                        likely visits next share a 128 B cache line; 0: the order given.  Hits do not depend on
                                        it.  Read by pt_scene_upload. */

@@ -296,9 +296,9 @@ _INSTANCED = {}
 
 def instanced_scene(pkg, width, height, instances, base="dragon.obj"):
     """The stress configuration: `instances` copies of the dragon stand-in (868,352 triangles each; 116 copies are
-    100.7 M triangles) on a square grid, flattened into ONE triangle mesh and one BVH as the reference would see it,
-    glossy, with glass spheres between the copies (the reference has one material per mesh, so glossy + glass means a
-    glossy mesh plus glass spheres), the dragon scene's plane and the forest map.  Returns (scene, triangle count)."""
+    100.7 M triangles) on a square grid in ONE BVH, the copies alternately glossy and glass (a mesh each, see
+    pt_scene_desc.meshes), glass spheres between them, the dragon scene's plane and the forest map.
+    Returns (scene, triangle count)."""
     import math
     side = int(math.ceil(math.sqrt(instances)))
     key = (instances, base)
@@ -328,8 +328,12 @@ def instanced_scene(pkg, width, height, instances, base="dragon.obj"):
                           width / height, 0.01, 2.2 * extent + 1.0)
     tex, marg, cond = hdr_env(pkg, "forest.hdr")
     planes = [pkg.make_plane((0, floor_y, 0), (0, 1, 0), (0.65, 0.1, 0.1, 0.0), pkg.DIFFUSE)]
+    # every copy is a mesh of its own in the one BVH: glossy and glass alternate
+    n = ntris // instances
+    meshes = [((0.65, 0.65, 0.65, 0.05), pkg.GLOSSY, k * n) if k % 2 == 0 else ((0.9, 1.0, 0.9, 1.5), pkg.GLASS, k * n)
+              for k in range(instances)]
     scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
-                            mesh_material=(0.65, 0.65, 0.65, 0.05), mesh_material_type=pkg.GLOSSY)
+                            mesh_material=(0.65, 0.65, 0.65, 0.05), mesh_material_type=pkg.GLOSSY, meshes=meshes)
     return scene, ntris
 
 
