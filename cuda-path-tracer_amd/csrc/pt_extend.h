@@ -56,6 +56,7 @@ struct RayState {
     float t;
     uint32_t hid;
     int node, sp;
+    int top0, top1;            // PT_REGTOP: the two topmost stack entries (top0 above top1), see stack_push
     uint32_t c_nodes, c_tris, c_leaves;
 };
 
@@ -91,6 +92,53 @@ __device__ __forceinline__ Stack<OVERFLOW> make_stack(int *lds_base, const Exten
     return s;
 }
 
+// The traversal stack of a ray.  Default: all entries in the lane's LDS column, R.sp = entries on the stack.
+// PT_REGTOP (compile-time, for A/B builds): the two topmost entries live in registers (R.top0 above R.top1) and only the
+// entries below them in the LDS column, which then needs two slots fewer; a pop hands out a register at once and refills
+// the lower register from LDS behind it.  Measured on MI355X (868 k-triangle stand-in, 1920x1080x512): see DESIGN.md.
+#ifndef PT_REGTOP
+#define PT_REGTOP 0
+#endif
+constexpr int kRegTop = PT_REGTOP ? 2 : 0;
+
+template <class STK>
+__device__ __forceinline__ void stack_reset(RayState &R, const STK &stk)
+{
+    if (PT_REGTOP) {
+        R.top0 = kSentinel;                 // bottom entry: popping it ends the traversal
+        R.top1 = kSentinel;
+    } else {
+        stk.put(0, kSentinel);
+    }
+    R.sp = 1;
+}
+
+template <class STK>
+__device__ __forceinline__ void stack_push(RayState &R, const STK &stk, int v)
+{
+    if (PT_REGTOP) {
+        if (R.sp >= 2) stk.put(R.sp - 2, R.top1);
+        R.top1 = R.top0;
+        R.top0 = v;
+    } else {
+        stk.put(R.sp, v);
+    }
+    R.sp++;
+}
+
+template <class STK>
+__device__ __forceinline__ int stack_pop(RayState &R, const STK &stk)
+{
+    R.sp--;
+    if (PT_REGTOP) {
+        const int v = R.top0;
+        R.top0 = R.top1;
+        if (R.sp >= 2) R.top1 = stk.get(R.sp - 2);
+        return v;
+    }
+    return stk.get(R.sp);
+}
+
 // What every ray needs before the tree: its closest hit among the planes and spheres (reference src/render.cu:25-33)
 // and the slab-test constants 1/d and -o/d (reference src/bvh.cuh:133-137), NaNs made positive.
 __device__ __forceinline__ void ray_setup(const DScene &sc, f3 o, f3 d, float &t, uint32_t &hid, f3 &inv, f3 &nood)
@@ -113,8 +161,7 @@ __device__ __forceinline__ void ray_begin(const DScene &sc, RayState &R, f3 o, f
     R.o = o;
     R.d = d;
     ray_setup(sc, o, d, R.t, R.hid, R.inv, R.nood);
-    stk.put(0, kSentinel);                  // bottom slot: popping it ends the traversal
-    R.sp = 1;
+    stack_reset(R, stk);
     R.node = sc.has_bvh ? 0 : kSentinel;
 }
 
@@ -188,14 +235,8 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
     int next = hl ? cl : cr;
     next = right_first ? cr : next;
     const int far_child = right_first ? cl : cr;
-    if (both) {
-        stk.put(R.sp, far_child);
-        R.sp++;
-    }
-    if (!(hl || hr)) {
-        R.sp--;
-        next = stk.get(R.sp);
-    }
+    if (both) stack_push(R, stk, far_child);
+    if (!(hl || hr)) next = stack_pop(R, stk);
     if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
     R.node = next;
 }
@@ -227,8 +268,7 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
     }
     int next = R.node + 1;
     if (flags & 1u) {
-        R.sp--;
-        next = stk.get(R.sp);
+        next = stack_pop(R, stk);
         if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
     }
     R.node = next;
@@ -327,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     R.c_nodes = R.c_tris = R.c_leaves = 0;
     R.node = kSentinel;
     R.sp = 1;
+    R.top0 = R.top1 = kSentinel;
     R.t = kFltMax;
     R.hid = PT_PRIM_MISS;
     R.o = R.d = R.inv = R.nood = mk3(0, 0, 0);

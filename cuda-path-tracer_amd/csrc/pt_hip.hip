@@ -768,7 +768,8 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
                          size_t *gstk_threads, const float4 *ro, const float4 *rd, uint32_t n_fixed, uint32_t n_upper,
                          uint32_t *hid, float *t)
 {
-    const uint32_t need = ctx->sc.has_bvh ? ctx->sc.stack_slots : 1;
+    // slots the LDS column has to hold: tree depth + 1, less what the kernel keeps in registers
+    const uint32_t need = ctx->sc.has_bvh ? std::max<uint32_t>(1, ctx->sc.stack_slots - std::min<uint32_t>(kRegTop, ctx->sc.stack_slots - 1)) : 1;
     const int lds_slots = gstk ? (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots) : (int)need;
     const bool overflow = need > (uint32_t)lds_slots;
     const int per_cu = std::max(1, std::min(ctx->extend_blocks, 160 / lds_slots));
