@@ -333,6 +333,15 @@ __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
     else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
+#ifdef PT_VALU_PAD
+    // sensitivity probe: PT_VALU_PAD extra vector instructions per step that change nothing
+    {
+        float pad = R.t;
+#pragma unroll
+        for (int k = 0; k < PT_VALU_PAD; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
+        asm volatile("" ::"v"(pad));
+    }
+#endif
     // Keep the record address in registers of its own until the step is over.  When the allocator lets it share
     // registers with one of the four loaded values, the next step's address computation has to wait for every
     // outstanding memory operation first (s_waitcnt vmcnt(0)) -- the streaming stores of rays retired at the last
