@@ -129,6 +129,11 @@ def main():
         torch.cuda.synchronize()
         D.render_and_reduce(render_fn, film, args.spp, seed=i)
 
+    if world > 1:
+        # the first collective on a communicator sets it up (hundreds of ms): do that outside the timed region even when
+        # no warm-up step was asked for
+        dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     acc = {k: 0 for k in acc}

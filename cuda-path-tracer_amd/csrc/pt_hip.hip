@@ -600,6 +600,10 @@ struct pt_ctx {
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
     size_t tmp_hid_n = 0;
+    float4 *stage_o = nullptr, *stage_d = nullptr, *stage_h = nullptr;   // device staging of pt_intersect (host rays)
+    float *stage_t = nullptr;
+    uint32_t *stage_id = nullptr;
+    uint64_t stage_cap = 0;
     unsigned char *scratch = nullptr;   // this device's copy of the static scratch array (pt_intersect_device_noalloc)
 
     // film
@@ -1137,6 +1141,8 @@ void pt_ctx_destroy(pt_ctx *ctx)
     (void)hipFree(ctx->cnt);
     (void)hipFree(ctx->gstk);
     (void)hipFree(ctx->tmp_hid);
+    (void)hipFree(ctx->stage_o); (void)hipFree(ctx->stage_d); (void)hipFree(ctx->stage_h);
+    (void)hipFree(ctx->stage_t); (void)hipFree(ctx->stage_id);
     (void)hipHostFree(ctx->h_cnt);
     (void)hipFree(ctx->slab);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
@@ -1530,28 +1536,28 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
     if (n == 0) return PT_OK;
     if (!org || !dir || !t_out || !prim_out) return fail(ctx, PT_ERR_ARG, "pt_intersect: NULL buffer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // rays go through the device in chunks of 2^20; the staging buffers belong to the context and are kept between calls
     const uint64_t chunk = 1u << 20;
-    float4 *d_o = nullptr, *d_d = nullptr, *d_h = nullptr;
-    float *d_t = nullptr;
-    uint32_t *d_id = nullptr;
     const uint64_t cap = std::min(n, chunk);
+    if (ctx->stage_cap < cap) {
+        for (void *p : {(void *)ctx->stage_o, (void *)ctx->stage_d, (void *)ctx->stage_h, (void *)ctx->stage_t, (void *)ctx->stage_id})
+            (void)hipFree(p);
+        ctx->stage_o = ctx->stage_d = ctx->stage_h = nullptr;
+        ctx->stage_t = nullptr;
+        ctx->stage_id = nullptr;
+        ctx->stage_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->stage_o, cap * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&ctx->stage_d, cap * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&ctx->stage_h, cap * sizeof(float4)));
+        HIPCHK(ctx, hipMalloc(&ctx->stage_t, cap * sizeof(float)));
+        HIPCHK(ctx, hipMalloc(&ctx->stage_id, cap * sizeof(uint32_t)));
+        ctx->stage_cap = cap;
+    }
+    float4 *d_o = ctx->stage_o, *d_d = ctx->stage_d, *d_h = ctx->stage_h;
+    float *d_t = ctx->stage_t;
+    uint32_t *d_id = ctx->stage_id;
     std::vector<float4> ho(cap), hd(cap), hh(cap);
     std::vector<float> ht(cap);
-    int rc = PT_OK;
-    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_h); (void)hipFree(d_t); (void)hipFree(d_id); };
-#define ICHK(call)                                                                                              \
-    do {                                                                                                        \
-        hipError_t e_ = (call);                                                                                 \
-        if (e_ != hipSuccess) {                                                                                 \
-            cleanup();                                                                                          \
-            return fail(ctx, PT_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                       \
-        }                                                                                                       \
-    } while (0)
-    ICHK(hipMalloc(&d_o, cap * sizeof(float4)));
-    ICHK(hipMalloc(&d_d, cap * sizeof(float4)));
-    ICHK(hipMalloc(&d_h, cap * sizeof(float4)));
-    ICHK(hipMalloc(&d_t, cap * sizeof(float)));
-    ICHK(hipMalloc(&d_id, cap * sizeof(uint32_t)));
     for (uint64_t base = 0; base < n; base += chunk) {
         const uint64_t m = std::min(chunk, n - base);
         for (uint64_t i = 0; i < m; i++) {
@@ -1559,16 +1565,17 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
             ho[i] = make_float4(po[0], po[1], po[2], 0);
             hd[i] = make_float4(pd[0], pd[1], pd[2], 0);
         }
-        ICHK(hipMemcpyAsync(d_o, ho.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        ICHK(hipMemcpyAsync(d_d, hd.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-        rc = launch_extend(ctx, ctx->stream, ctx->cnt, false, &ctx->gstk, &ctx->gstk_threads, d_o, d_d, (uint32_t)m,
-                           (uint32_t)m, d_id, d_t);
-        if (rc != PT_OK) { cleanup(); return rc; }
+        HIPCHK(ctx, hipMemcpyAsync(d_o, ho.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_d, hd.data(), m * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        const int rc = launch_extend(ctx, ctx->stream, ctx->cnt, false, &ctx->gstk, &ctx->gstk_threads, d_o, d_d, (uint32_t)m,
+                                     (uint32_t)m, d_id, d_t);
+        if (rc != PT_OK) return rc;
         hipLaunchKernelGGL(k_hit_expand, dim3(stream_grid(ctx, m)), dim3(kBlock), 0, ctx->stream, ctx->sc, d_o, d_d, d_id, d_t,
                            (uint32_t)m, d_h);
-        ICHK(hipMemcpyAsync(hh.data(), d_h, m * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        ICHK(hipMemcpyAsync(ht.data(), d_t, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        ICHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(hh.data(), d_h, m * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ht.data(), d_t, m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (uint64_t i = 0; i < m; i++) {
             t_out[base + i] = ht[i];
             uint32_t p;
@@ -1581,8 +1588,6 @@ int pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir, fl
             }
         }
     }
-#undef ICHK
-    cleanup();
     return PT_OK;
 }
 
