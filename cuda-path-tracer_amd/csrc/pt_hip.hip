@@ -154,6 +154,22 @@ __device__ __forceinline__ void lambert_weight(f3 n3, f3 out, float4 mat, float4
     th.x *= mat.x * s; th.y *= mat.y * s; th.z *= mat.z * s;
 }
 
+// Shades the hit (t, hid) of the ray (o, d) of path (pixel, sample) at bounce k: material and normal of the hit, the hit
+// point, the new direction (everything of shade_dir; the Lambertian weight is left to the caller, see lambert_weight).
+__device__ __forceinline__ void shade_hit(const DScene &sc, f3 o, f3 d, float t, uint32_t hid, uint32_t pixel, uint32_t sample,
+                                          uint32_t k, uint32_t seed0, uint32_t seed1, float4 &th, f3 &out, f3 &hitp, f3 &n3,
+                                          float4 &mat, bool &lambert)
+{
+    uint32_t mat_type;
+    material_of(sc, hid, mat, mat_type);
+    const int slot = mat_slot(mat_type);
+    uint32_t prim;
+    n3 = hit_normal(sc, hid, o, d, t, prim);
+    hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
+    Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
+    out = shade_dir(sc, slot, d, n3, mat, rng, th, lambert);
+}
+
 // --------------------------------------------------------------------------------------------------------------
 // bounce = logic (reference src/render.cu:49-89) + shade of the surviving paths, in one pass over the ray buffer.
 //
@@ -164,6 +180,88 @@ __device__ __forceinline__ void lambert_weight(f3 n3, f3 out, float4 mat, float4
 // kBounceBlock threads claims its output range with ONE atomic, because every block adds to the same counter and
 // same-address atomics are what this kernel would otherwise wait for.
 // --------------------------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------------------------
+// A ray whose closest hit is known, and one step of its path.
+struct PathRay {
+    f3 o, d;
+    float t;            // hit distance, FLT_MAX on a miss
+    uint32_t hid;       // hit id as extend stores it
+    float4 th;          // throughput rgb, w = sample | bounce << 27
+};
+
+enum { RAY_DROP = 0, RAY_FRONT = 1, RAY_BACK = 2, RAY_ESCAPED = 3 };
+
+// logic (reference src/render.cu:49-89) + shade (src/render.cu:129-242) of ONE ray of a path: ends the path (miss, depth
+// limit, Russian roulette) or shades the hit, stores the escape value of the ray the path continues with in the path's
+// slab entry, and runs the traversal's first step on that ray.  Returns what became of the path: RAY_DROP it ended
+// (its slab entry holds what it adds to the film); RAY_ESCAPED the new ray leaves the scene at once, so the path ended
+// too; RAY_BACK the new ray's closest hit is a plane or sphere in front of the mesh and is known (R.t, R.hid);
+// RAY_FRONT the new ray needs the tree.  In the last two cases R is the new ray.
+// A camera ray (bounce 0) that missed has no escape value in the slab yet (see k_generate): it is written here.
+__device__ __forceinline__ int path_step(const DScene &sc, PathRay &R, uint32_t pixel, float4 *__restrict__ slab_entry,
+                                         uint32_t seed0, uint32_t seed1)
+{
+    const uint32_t sk = __float_as_uint(R.th.w);
+    const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
+    float4 th = R.th;
+    bool alive = false;
+    const bool late_miss = R.t == kFltMax && k == 0;
+    if (!(R.t == kFltMax || 2 * k >= kMaxDepth)) {
+        alive = true;
+        if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
+            Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
+            const float p = fmaxf(th.x, fmaxf(th.y, th.z));
+            if (rng.next() > p) {
+                alive = false;
+                st_stream(slab_entry, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            } else {
+                const float ip = 1 / p;
+                th.x *= ip; th.y *= ip; th.z *= ip;
+            }
+        }
+    }
+    f3 out = R.d, hitp = R.o, n3 = R.o;
+    float4 mat = make_float4(0, 0, 0, 0);
+    bool lambert = false;
+    if (alive) shade_hit(sc, R.o, R.d, R.t, R.hid, pixel, sample, k, seed0, seed1, th, out, hitp, n3, mat, lambert);
+    if (alive || late_miss) {
+        // one environment lookup serves both: the new ray's direction, or the direction of the camera ray that missed
+        const float4 e = env_lookup(sc, out);
+        if (lambert) lambert_weight(n3, out, mat, e, th);
+        st_stream(slab_entry, escape_value(th, e));
+    }
+    if (!alive) return RAY_DROP;
+    th.w = __uint_as_float(sample | ((k + 1) << 27));
+    // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
+    // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that hits a
+    // plane or sphere in front of the mesh has its hit known now and skips extend.
+    float nt;
+    uint32_t nhid;
+    const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
+    R.o = hitp; R.d = out; R.t = nt; R.hid = nhid; R.th = th;
+    return !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+}
+
+// Steps a path for as long as the ray it continues with is settled where it is made (at most kPathTrips steps): such a
+// ray would otherwise be written to the path buffer with its hit (48 + 8 B), read back by the next bounce launch (56 B)
+// and shaded there.  `consumed` counts the settled rays that were shaded here instead (per lane; they take no slot but
+// are rays all the same).  The film does not depend on where a ray is shaded: random numbers are keyed on the path.
+#ifndef PT_PATH_TRIPS
+#define PT_PATH_TRIPS 1
+#endif
+constexpr int kPathTrips = PT_PATH_TRIPS;
+__device__ __forceinline__ int path_run(const DScene &sc, PathRay &R, uint32_t pixel, float4 *__restrict__ slab_entry,
+                                        uint32_t seed0, uint32_t seed1, uint32_t &consumed)
+{
+    int cls;
+    for (int trip = 0;; trip++) {
+        cls = path_step(sc, R, pixel, slab_entry, seed0, seed1);
+        if (cls != RAY_BACK || trip + 1 == kPathTrips) break;
+        consumed++;
+    }
+    return cls;
+}
+
 // threads per block = rays per output claim.  The threads of a block move in lock step (two barriers per batch), so a
 // smaller block lets more of the gathers of different batches overlap; a larger one needs fewer of the same-address
 // atomics, which all blocks of all kernels of a stream share.  Measured ms per frame (868 k-triangle stand-in / spheres
@@ -208,8 +306,6 @@ __device__ __forceinline__ BounceIn bounce_load(const PathBuf &A, uint32_t i, ui
 // one thread claims the block's front and back ranges with ONE 64-bit atomic, and escaped rays are only counted in a
 // wave-uniform register that flush_escaped adds once, when the kernel ends.
 // Two barriers; s_wave/s_base are double-buffered by `par` so that consecutive calls need no third one.
-enum { RAY_DROP = 0, RAY_FRONT = 1, RAY_BACK = 2, RAY_ESCAPED = 3 };
-
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_append(int cls, Counters *cnt, uint32_t P, uint32_t (&s_wave)[2][BLOCK / 64],
                                                  unsigned long long (&s_base)[2], int par, uint32_t &escaped)
@@ -240,10 +336,13 @@ __device__ __forceinline__ uint32_t block_append(int cls, Counters *cnt, uint32_
                      __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask, 0)));
 }
 
-// adds a wave's count of escaped rays to the iteration's counter (once per wave and kernel)
-__device__ __forceinline__ void flush_escaped(Counters *cnt, uint32_t escaped)
+// adds a wave's count of rays that were settled without taking a slot to the iteration's counter (once per wave and
+// kernel): `escaped` is the same in every lane (block_append counts with ballots), `consumed` is each lane's own count
+__device__ __forceinline__ void flush_escaped(Counters *cnt, uint32_t escaped, uint32_t consumed)
 {
-    if ((threadIdx.x & 63u) == 0 && escaped) atomicAdd(&cnt->n_escaped, escaped);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) consumed += __shfl_xor(consumed, off, 64);
+    if ((threadIdx.x & 63u) == 0 && escaped + consumed) atomicAdd(&cnt->n_escaped, escaped + consumed);
 }
 
 // waves_per_eu(5): 96 VGPRs instead of 103, a fifth wave per SIMD where the kernel has the CU to itself (no spills;
@@ -255,7 +354,7 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
 {
     __shared__ uint32_t s_wave[2][kBounceBlock / 64];
     __shared__ unsigned long long s_base[2];
-    uint32_t escaped = 0;
+    uint32_t escaped = 0, consumed = 0;
     const uint32_t n_front = cnt->n_in;
     const uint32_t n = n_front + cnt->n_back_in;
     const uint32_t stride = gridDim.x * kBounceBlock;
@@ -268,75 +367,26 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
         // of one batch overlap the gathers of the one before (3 % of a frame without triangles, nothing with)
         const BounceIn in = nxt;
         nxt = bounce_load(A, i + stride, (uint64_t)first + stride < n ? n : 0u, n_front, P);
-        bool alive = false;
-        float4 th = in.th;
-        const float4 d4 = in.d4, o4 = in.o4;
-        const float t = in.t;
-        const uint32_t hid = in.hid;
-        const uint32_t sk = __float_as_uint(th.w);
-        const uint32_t sample = sk & 0x07FFFFFFu, k = sk >> 27;
-        const uint32_t pixel = __float_as_uint(d4.w);
-        // A miss or the depth limit ends the path with the escape value its slab entry already holds -- except a camera ray
-        // that went through the tree and missed: the generate kernel leaves that entry to be written here.
-        const bool late_miss = i < n && t == kFltMax && k == 0;
-        if (!(t == kFltMax || 2 * k >= kMaxDepth)) {
-            alive = true;
-            if (2 * k + 1 >= kMinDepth) {                       // Russian roulette (src/render.cu:78-86)
-                Rng rng(pixel, sample, k, STAGE_LOGIC, seed0, seed1);
-                const float p = fmaxf(th.x, fmaxf(th.y, th.z));
-                if (rng.next() > p) {
-                    alive = false;
-                    st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                } else {
-                    const float ip = 1 / p;
-                    th.x *= ip; th.y *= ip; th.z *= ip;
-                }
-            }
-        }
-        f3 out = mk3(0, 0, 0), hitp = out;
+        PathRay R;
+        R.o = xyz(in.o4); R.d = xyz(in.d4); R.t = in.t; R.hid = in.hid; R.th = in.th;
+        const uint32_t pixel = __float_as_uint(in.d4.w);
         int cls = RAY_DROP;
-        float nt = kFltMax;
-        uint32_t nhid = PT_PRIM_MISS;
-        f3 n3 = out;
-        float4 mat = make_float4(0, 0, 0, 0);
-        bool lambert = false;
-        if (alive) {
-            uint32_t mat_type;
-            material_of(sc, hid, mat, mat_type);
-            const int slot = mat_slot(mat_type);
-            const f3 o = xyz(o4), d = xyz(d4);
-            uint32_t prim;
-            n3 = hit_normal(sc, hid, o, d, t, prim);
-            hitp = mk3(__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z));
-            Rng rng(pixel, sample, k, STAGE_SHADE, seed0, seed1);
-            out = shade_dir(sc, slot, d, n3, mat, rng, th, lambert);
-        }
-        if (alive || late_miss) {
-            // one environment lookup serves both: the new ray's direction, or the direction of the camera ray that missed
-            const float4 e = env_lookup(sc, alive ? out : xyz(d4));
-            if (lambert) lambert_weight(n3, out, mat, e, th);
-            st_stream(slab + (size_t)(sample - slab_first_sample) * npix + pixel, escape_value(th, e));
-        }
-        if (alive) {
-            th.w = __uint_as_float(sample | ((k + 1) << 27));
-            // The traversal's first step, here: a new ray that leaves the scene at once ends its path (its escape value is
-            // already in the slab; the ray needs no slot, no traversal and no pass through the next bounce), one that
-            // hits a plane or sphere in front of the mesh gets its hit stored now and skips extend.
-            const bool settled = ray_settled_at_root(sc, hitp, out, nt, nhid);
-            cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
+        if (i < n) {
+            const uint32_t sample = __float_as_uint(in.th.w) & 0x07FFFFFFu;
+            cls = path_run(sc, R, pixel, slab + (size_t)(sample - slab_first_sample) * npix + pixel, seed0, seed1, consumed);
         }
         const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par, escaped);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
-            st_stream(B.o + dst, make_float4(hitp.x, hitp.y, hitp.z, 0.0f));
-            st_stream(B.d + dst, make_float4(out.x, out.y, out.z, d4.w));
-            st_stream(B.thr + dst, th);
+            st_stream(B.o + dst, make_float4(R.o.x, R.o.y, R.o.z, 0.0f));
+            st_stream(B.d + dst, make_float4(R.d.x, R.d.y, R.d.z, in.d4.w));
+            st_stream(B.thr + dst, R.th);
             if (cls == RAY_BACK) {
-                st_stream(B.hid + dst, nhid);
-                st_stream(B.t + dst, nt);
+                st_stream(B.hid + dst, R.hid);
+                st_stream(B.t + dst, R.t);
             }
         }
     }
-    flush_escaped(cnt, escaped);
+    flush_escaped(cnt, escaped, consumed);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -365,7 +415,7 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
 {
     __shared__ uint32_t s_wave[2][kGenBlock / 64];
     __shared__ unsigned long long s_base[2];
-    uint32_t escaped = 0;
+    uint32_t escaped = 0, consumed = 0;
     const uint32_t take = cnt->take;
     const unsigned long long first = cnt->gen_first;
     const uint32_t npix = W * H;
@@ -401,11 +451,23 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
             // gets its hit stored now
             const bool settled = ray_settled_at_root(sc, o, d, nt, nhid);
             cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
-            // The path's slab entry is only needed now if the path ends now.  A camera ray that hits something has its entry
-            // written when it is shaded (the first hit is never cut by depth or roulette), and one that goes through the
-            // tree and misses has it written by the bounce kernel when it finds the miss: waves whose pixels all show
-            // geometry skip the environment lookup (two inverse trigonometric functions and four texels) altogether.
-            if (cls == RAY_ESCAPED) st_stream(slab + (size_t)s_local * npix + pixel, escape_value(th, env_lookup(sc, d)));
+            // A camera ray that is settled here is dealt with here, exactly as the bounce kernel would one iteration later.
+            // One that leaves the scene: its path ends, path_step writes its slab entry.  One whose hit is a plane or sphere
+            // in front of the mesh: it is shaded now (and so is what follows, while that is settled too), so the path leaves
+            // this kernel with a later ray and the camera ray's trip through the path buffers is saved.
+            // A camera ray that needs the tree gets its slab entry from the bounce kernel (when it is shaded, or when the
+            // tree reports a miss): waves whose pixels all show the mesh skip the environment lookup altogether.
+            if (cls != RAY_FRONT) {
+                PathRay R;
+                R.o = o; R.d = d; R.t = nt; R.hid = nhid; R.th = th;
+                const bool hit = cls == RAY_BACK;
+                consumed += hit ? 1u : 0u;
+                const int c = path_run(sc, R, pixel, slab + (size_t)s_local * npix + pixel, seed0, seed1, consumed);
+                if (hit) {
+                    cls = c;
+                    o = R.o; d = R.d; th = R.th; nt = R.t; nhid = R.hid;
+                }
+            }
         }
         const uint32_t dst = block_append<kGenBlock>(cls, cnt, P, s_wave, s_base, par, escaped);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
@@ -421,7 +483,7 @@ __global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Co
         s_local += stride_s;
         if (r >= npix) { r -= npix; s_local++; }
     }
-    flush_escaped(cnt, escaped);
+    flush_escaped(cnt, escaped, consumed);
 }
 
 // one thread, after generate: the rays appended at the front become the extend kernel's input.  A ray that was settled
