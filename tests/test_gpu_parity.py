@@ -435,6 +435,31 @@ def test_render_small_pool_many_iterations(pkg, ctx):
     assert np.array_equal(small, big), "the film depends on the pool size"
 
 
+def test_render_film_size_that_does_not_tile(pkg, ctx):
+    """50x30 is not a multiple of the 8x4 pixel tiles: paths are enumerated row by row instead, the per-launch index
+    arithmetic (one division per thread, then additions with carry) wraps many times with a 1024-slot pool, and the film
+    must still be the oracle's and must not depend on the pool."""
+    W, H, spp = 50, 30, 5
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    films = []
+    try:
+        for pool in (1 << 22, 1024, 4096 + 512):
+            ctx.set_option(pkg.OPT_POOL_SIZE, pool)
+            ctx.film_clear()
+            st = ctx.render(0, spp, spp, seed=13)
+            assert st.paths == W * H * spp
+            films.append(ctx.film_download())
+    finally:
+        ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=13)
+    assert abs(int(st.rays) - int(ost.rays)) <= 0.004 * ost.rays
+    _, differing = film_metrics(films[0], ofilm)
+    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+
+
 def test_packed_environment_texels_change_nothing(pkg):
     """A map decoded from a Radiance .hdr file is kept as 8-byte texels (shared-exponent rgb + pdf); the film is bit
     for bit the one rendered from the 16-byte float texels.  A map of arbitrary floats is not packed."""
