@@ -13,7 +13,10 @@
  * for its four shipped meshes (reference src/bvh.cu:298,302) -- the FNV-1a-64
  * hashes recorded with those counts could NOT be reproduced, so the buffer
  * contents themselves are unpinned; (3) traversal + triangle test against an
- * independent float64 brute force.  Everything else on the device side
+ * independent float64 brute force; (4) the RGBE pixel decode against the
+ * reference's own vendored reader (stb_image, compiled from the reference
+ * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz).
+ * Everything else on the device side
  * (visit order details, shading, environment lookup) is "parity unpinned":
  * the reference ships no tests, fixtures or golden outputs for it and cannot
  * be built here (CUDA toolkit, cuRAND, inline PTX), so it is restated from
