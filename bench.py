@@ -281,6 +281,11 @@ def main():
                     "record_rate_ceiling": prof.get("record_rate_ceiling"),
                     "frac_of_record_rate_ceiling": None if not (prof.get("record_rate_ceiling") and roof.get("records_per_s"))
                     else round(roof["records_per_s"] / prof["record_rate_ceiling"], 4),
+                    # a bare gather loop at extend's own mix and lane occupancy, and extend's rate when it runs alone
+                    # (one stream, from the same profile run): how much of the memory pipeline's rate the kernel reaches
+                    "probe_at_extend_mix_records_per_s": None if not prof.get("probe_mixed_g_records_per_s")
+                    else prof["probe_mixed_g_records_per_s"] * 1e9,
+                    "extend_alone_records_per_s": prof.get("extend_alone_records_per_s"),
                 }
             out["roofline"] = roof
         else:

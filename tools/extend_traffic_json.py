@@ -58,6 +58,12 @@ ext_ms_1, calls_1 = kernel_total_ms(os.path.join(src, "kernel_stats_one_stream.t
 frames_1 = bench_line(os.path.join(src, "bench_one_stream.log"))
 frames_in_trace = frames_1["steps"] + frames_1["warmup"]
 pr = probe(os.path.join(src, "gather_probe.txt"))
+mixed = None
+if os.path.exists(os.path.join(src, "gather_probe_mixed.txt")):
+    for line in open(os.path.join(src, "gather_probe_mixed.txt")):
+        m = re.match(r"mode 0:\s+[0-9.]+ ms\s+([0-9.]+) G records/s", line)
+        if m:
+            mixed = float(m.group(1))
 r_l1, r_l2, r_fab = pr[400], pr[16000], pr[1300000]
 
 disp = c["_dispatches"]
@@ -102,6 +108,11 @@ out = {
         min(r_l1, r_l2 / (1 - l1_hit), r_fab / f_fab))],
     # the same three rates chained one after the other (a ray's next fetch waits for this one)
     "record_rate_serial_model": round(1e9 / (f_l1 / r_l1 + f_l2 / r_l2 + f_fab / r_fab)),
+    # a bare dependent-gather loop with extend's own mix and lane occupancy (41 of 64 lanes, 38 % L1 set, 41 % L2 set)
+    "probe_mixed_g_records_per_s": mixed,
+    # records extend fetches per frame (node visits + triangle tests of the rays that reach it) over its one-stream time
+    "extend_alone_records_per_s": round(((tm["nodes"] + tm["tris"]) * b["config"]["rays_per_frame"]
+                                         - b["config"]["rays_escaped_at_creation_per_frame"]) / (ext_ms_frame * 1e-3)),
     "algorithmic_bytes_per_ray": tm["bytes_per_ray"],
     "nodes_per_ray": tm["nodes"],
     "tris_per_ray": tm["tris"],
@@ -117,6 +128,8 @@ with open(os.path.join(dst, prefix + "_pmc_kernels.txt"), "w") as fh:
         fh.write(open(os.path.join(src, "pmc_%s.txt" % k)).read())
 for a, bname in (("bench_default.log", "bench_default.log"), ("kernel_stats.txt", "bench_default_kernel_stats.txt"),
                  ("kernel_stats_one_stream.txt", "kernel_stats_one_stream.txt"),
-                 ("bench_one_stream.log", "bench_one_stream.log"), ("gather_probe.txt", "gather_probe.txt")):
-    shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + "_" + bname))
+                 ("bench_one_stream.log", "bench_one_stream.log"), ("gather_probe.txt", "gather_probe.txt"),
+                 ("gather_probe_mixed.txt", "gather_probe_mixed.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, prefix + "_" + bname))
 print(json.dumps(out, indent=1))

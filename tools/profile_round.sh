@@ -21,3 +21,6 @@ python3 tools/pmc_sum.py gpurun_out/$tag/pmc k_generate > gpurun_out/$tag/pmc_ge
 cat gpurun_out/$tag/pmc_extend.txt
 for n in 400 16000 1300000; do echo "records $n"; timeout -k 5 60 tools/gather_probe $n 2000 26624 || exit 1; done > gpurun_out/$tag/gather_probe.txt 2>&1
 cat gpurun_out/$tag/gather_probe.txt
+# the same fetches at extend's own mix: 41 of 64 lanes busy, 38 % from an L1-resident set, 41 % from an L2-resident one
+timeout -k 5 60 tools/gather_probe2 41 38 41 > gpurun_out/$tag/gather_probe_mixed.txt 2>&1 || exit 1
+cat gpurun_out/$tag/gather_probe_mixed.txt
