@@ -409,7 +409,10 @@ __global__ void k_take(Counters *cnt, uint32_t P)
 #define PT_GENBLOCK 512
 #endif
 constexpr int kGenBlock = PT_GENBLOCK;
-__global__ __launch_bounds__(kGenBlock) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t P, uint32_t W,
+// waves_per_eu(6): 80 VGPRs (8 B of scratch per lane) instead of 98, a sixth wave per SIMD for the gathers of the camera
+// hits that are shaded here.  Measured with bounce at 5 / 6 and generate at 5 / 6 waves: 240.9 ms (5, 5), 238.5 (5, 6),
+// 243.1 (6, 5), 240.6 (6, 6), 249.3 (7, 7) on the 868 k-triangle frame.
+__global__ __launch_bounds__(kGenBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_generate(DScene sc, PathBuf B, Counters *cnt, uint32_t P, uint32_t W,
                                                      uint32_t H, FastDiv row_div, uint32_t spp_begin, uint32_t seed0,
                                                      uint32_t seed1, float4 *__restrict__ slab)
 {
