@@ -405,8 +405,11 @@ __global__ void k_take(Counters *cnt, uint32_t P)
     cnt->paths_total += take;
 }
 
+// threads per block = paths per output claim.  512 while the kernel only made camera rays; since it also shades the camera
+// hits that are settled here (gathers, like bounce) 256: 234.6 ms against 238.8 (512), 243.7 (1024), 244.6 (128) on the
+// 868 k-triangle frame, 51.0 against 55.3 on the spheres-only frame.
 #ifndef PT_GENBLOCK
-#define PT_GENBLOCK 512
+#define PT_GENBLOCK 256
 #endif
 constexpr int kGenBlock = PT_GENBLOCK;
 // waves_per_eu(6): 80 VGPRs (8 B of scratch per lane) instead of 98, a sixth wave per SIMD for the gathers of the camera
