@@ -618,6 +618,14 @@ static hipError_t scratch_on_device(int device, unsigned char **out)
 // lanes of a context run side by side: the traversal kernel is bound by record fetches through the caches, bounce and
 // generate by streaming state through HBM, so one lane's extend runs beside another lane's bounce.  Measured on the
 // headline frame, 1 / 2 / 3 / 4 lanes: 324 / 280 / 269 / 288 ms.
+// blocks per CU the grids of bounce and generate are capped at (their blocks loop over the rays)
+#ifndef PT_BOUNCE_PER_CU
+#define PT_BOUNCE_PER_CU 8
+#endif
+#ifndef PT_GEN_PER_CU
+#define PT_GEN_PER_CU 8
+#endif
+constexpr int kBouncePerCu = PT_BOUNCE_PER_CU, kGenPerCu = PT_GEN_PER_CU;
 constexpr int kMaxLanes = 4;
 struct Lane {
     hipStream_t stream = nullptr;
@@ -916,13 +924,13 @@ static int lane_iterate(pt_ctx *ctx, Lane &ln, uint32_t s0, uint32_t s1)
     const uint32_t W = ctx->W, H = ctx->H, npix = W * H, P = ln.P;
     hipStream_t ls = ln.stream;
     PathBuf A = ln.buf[ln.cur], B = ln.buf[ln.cur ^ 1];
-    const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kBounceBlock),
+    const int gb = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * kBouncePerCu,
                                                                  ((uint64_t)P + kBounceBlock - 1) / kBounceBlock));
     if (ln.it > 0)
         hipLaunchKernelGGL(k_bounce, dim3(gb), dim3(kBounceBlock), 0, ls, ctx->sc, A, B, ln.cnt, P, ln.slab,
                            (uint32_t)ln.first, npix, s0, s1);
     hipLaunchKernelGGL(k_take, dim3(1), dim3(64), 0, ls, ln.cnt, P);
-    const int gg = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * (2048 / kGenBlock),
+    const int gg = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * kGenPerCu,
                                                                  ((uint64_t)P + kGenBlock - 1) / kGenBlock));
     hipLaunchKernelGGL(k_generate, dim3(gg), dim3(kGenBlock), 0, ls, ctx->sc, B, ln.cnt, P, W, H,
                        make_fastdiv(pixel_divisor(W, H)), (uint32_t)ln.first, s0, s1, ln.slab);
