@@ -4,7 +4,7 @@
 //   mode 0  every lane loads its own record with four 16 B loads
 //   mode 1  the four lanes of a quad load each of the quad's records together (one 64 B segment per quad and load), then
 //           a 4x4 transpose inside the quad gives every lane its record
-// usage: gather_probe2 [active_lanes] [l1_share_percent] [l2_share_percent] [steps]
+// usage: gather_probe2 [active_lanes] [l1_share_percent] [l2_share_percent] [steps] [blocks_per_cu]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -106,17 +106,19 @@ int main(int argc, char **argv)
     float4 *recs; uint32_t *out;
     CHECK(hipMalloc(&recs, h.size() * 4));
     CHECK(hipMemcpy(recs, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    const int blocks = 256 * 6;
+    const int per_cu = argc > 5 ? atoi(argv[5]) : 6;
+    const int blocks = 256 * per_cu;
+    const int lds_bytes = (160 * 1024 / per_cu) & ~1023;
     CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> res0((size_t)blocks * 256), res1(res0.size());
-    printf("active lanes %u of 64, L1 set %u %%, L2 set %u %%, rest from a 64 MB set\n", active, p1, p2);
+    printf("active lanes %u of 64, %d blocks per CU, L1 set %u %%, L2 set %u %%, rest from a 64 MB set\n", active, per_cu, p1, p2);
     for (int mode = 0; mode < 2; mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), 26624, 0, recs, steps, out, active, t1, t2);
-            else hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), 26624, 0, recs, steps, out, active, t1, t2);
+            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
+            else hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
