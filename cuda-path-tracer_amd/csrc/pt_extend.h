@@ -95,7 +95,8 @@ __device__ __forceinline__ Stack<OVERFLOW> make_stack(int *lds_base, const Exten
 // The traversal stack of a ray.  Default: all entries in the lane's LDS column, R.sp = entries on the stack.
 // PT_REGTOP (compile-time, for A/B builds): the two topmost entries live in registers (R.top0 above R.top1) and only the
 // entries below them in the LDS column, which then needs two slots fewer; a pop hands out a register at once and refills
-// the lower register from LDS behind it.  Measured on MI355X (868 k-triangle stand-in, 1920x1080x512): see DESIGN.md.
+// the lower register from LDS behind it.  Measured on MI355X (868 k-triangle stand-in, 1920x1080x512): 244.8 ms per frame
+// against 241.4 with the pure LDS column; the shifts cost 17 % more vector instructions and the two slots buy no block.
 #ifndef PT_REGTOP
 #define PT_REGTOP 0
 #endif
