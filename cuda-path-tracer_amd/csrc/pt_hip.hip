@@ -1358,10 +1358,19 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                             bad[part] == 1 ? "child out of range"
                                            : (bad[part] == 2 ? "leaf run leaves the triangle buffer" : "truncated triangle"));
         // record index of every run: nodes first, then the record nothing can hit, then the runs in node order
-        std::vector<uint64_t> run_at(2 * N + 1);
-        run_at[0] = N + 1;
-        for (uint64_t k = 0; k < 2 * N; k++) run_at[k + 1] = run_at[k] + run[k];
-        const uint64_t total_recs = run_at[2 * N];
+        // With the line-aware layout the two-triangle runs come first, each starting on an even record index, so that
+        // both records of such a leaf share one 128 B line; the other runs follow (no record is wasted either way).
+        std::vector<uint64_t> run_at(2 * N);
+        uint64_t total_recs = N + 1;
+        if (ctx->node_layout == 1) {
+            total_recs += total_recs & 1;                                   // at most one unused record
+            for (uint64_t k = 0; k < 2 * N; k++)
+                if (run[k] == 2) { run_at[k] = total_recs; total_recs += 2; }
+            for (uint64_t k = 0; k < 2 * N; k++)
+                if (run[k] != 2) { run_at[k] = total_recs; total_recs += run[k]; }
+        } else {
+            for (uint64_t k = 0; k < 2 * N; k++) { run_at[k] = total_recs; total_recs += run[k]; }
+        }
         if (total_recs >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
         HostArray<float4> recs(total_recs * 4);
         if (!recs.p) return fail(ctx, PT_ERR_NOMEM, "pt_scene_upload: out of host memory");
@@ -1372,6 +1381,8 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
             const uint32_t m[2] = {PT_PRIM_MISS, 3u};
             std::memcpy(&meta, m, 8);
             nohit[3] = meta;
+            // the record the alignment of the two-triangle runs may leave unused: never referenced, but defined
+            if (N + 2 <= total_recs) std::memcpy(recs.p + (N + 1) * 4, nohit, 64);
         }
         std::vector<uint32_t> mesh_first;
         if (many_meshes)
