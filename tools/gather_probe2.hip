@@ -4,6 +4,7 @@
 //   mode 0  every lane loads its own record with four 16 B loads
 //   mode 1  the four lanes of a quad load each of the quad's records together (one 64 B segment per quad and load), then
 //           a 4x4 transpose inside the quad gives every lane its record
+//   mode 2  as mode 1 without the transpose: what the load side alone could gain (results meaningless)
 // usage: gather_probe2 [active_lanes] [l1_share_percent] [l2_share_percent] [steps] [blocks_per_cu]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -64,22 +65,24 @@ __global__ __launch_bounds__(256) void k_probe(const float4 *__restrict__ recs, 
             }
         } else {
             const uint32_t j = lane & 3u;
-            const uint32_t want = on ? idx : 0xFFFFFFFFu;
+            // every lane of a quad takes part in all four loads; a lane without work still names a (valid) record
+            const uint32_t want = idx;
             const uint32_t i0 = __builtin_amdgcn_update_dpp(0, (int)want, 0x00, 0xF, 0xF, true);
             const uint32_t i1 = __builtin_amdgcn_update_dpp(0, (int)want, 0x55, 0xF, 0xF, true);
             const uint32_t i2 = __builtin_amdgcn_update_dpp(0, (int)want, 0xAA, 0xF, 0xF, true);
             const uint32_t i3 = __builtin_amdgcn_update_dpp(0, (int)want, 0xFF, 0xF, 0xF, true);
-            const float4 z = make_float4(0, 0, 0, 0);
-            r[0] = i0 != 0xFFFFFFFFu ? recs[(size_t)i0 * 4 + j] : z;
-            r[1] = i1 != 0xFFFFFFFFu ? recs[(size_t)i1 * 4 + j] : z;
-            r[2] = i2 != 0xFFFFFFFFu ? recs[(size_t)i2 * 4 + j] : z;
-            r[3] = i3 != 0xFFFFFFFFu ? recs[(size_t)i3 * 4 + j] : z;
+            r[0] = recs[(size_t)i0 * 4 + j];
+            r[1] = recs[(size_t)i1 * 4 + j];
+            r[2] = recs[(size_t)i2 * 4 + j];
+            r[3] = recs[(size_t)i3 * 4 + j];
+            if (MODE == 1) {
             float x[4] = {r[0].x, r[1].x, r[2].x, r[3].x}; quad_transpose(x, lane);
             float y[4] = {r[0].y, r[1].y, r[2].y, r[3].y}; quad_transpose(y, lane);
             float zz[4] = {r[0].z, r[1].z, r[2].z, r[3].z}; quad_transpose(zz, lane);
             float w[4] = {r[0].w, r[1].w, r[2].w, r[3].w}; quad_transpose(w, lane);
 #pragma unroll
             for (int c = 0; c < 4; c++) r[c] = make_float4(x[c], y[c], zz[c], w[c]);
+            }
         }
         uint32_t h = 0;
 #pragma unroll
@@ -114,18 +117,19 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> res0((size_t)blocks * 256), res1(res0.size());
     printf("active lanes %u of 64, %d blocks per CU, L1 set %u %%, L2 set %u %%, rest from a 64 MB set\n", active, per_cu, p1, p2);
-    for (int mode = 0; mode < 2; mode++) {
+    for (int mode = 0; mode < 3; mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
-            else hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
+            else if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
+            else hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             const double fetches = (double)blocks * 256 * steps * active / 64.0;
             if (rep) printf("mode %d: %8.3f ms  %7.2f G records/s\n", mode, ms, fetches / ms * 1e-6);
         }
-        CHECK(hipMemcpy(mode == 0 ? res0.data() : res1.data(), out, res0.size() * 4, hipMemcpyDeviceToHost));
+        if (mode < 2) CHECK(hipMemcpy(mode == 0 ? res0.data() : res1.data(), out, res0.size() * 4, hipMemcpyDeviceToHost));
     }
     size_t bad = 0;
     for (size_t i = 0; i < res0.size(); i++) bad += res0[i] != res1[i];
