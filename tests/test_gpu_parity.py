@@ -93,6 +93,44 @@ def test_both_extend_kernels_give_identical_hits(pkg, ctx):
         ctx.set_option(pkg.OPT_EXTEND_MODE, 2)
 
 
+def test_traversal_tuning_changes_no_answer(pkg, ctx):
+    """The traversal stack's split (LDS column + overflow in global memory for what a deep tree needs beyond it), the
+    refill threshold, the blocks per CU, the chunk order and the node order at upload are tuning: with any of them the hits
+    must equal the fixture bit for bit and the film must not change by a bit.  4 LDS slots on a tree 16 deep sends most of
+    every ray's stack through the overflow."""
+    W, H, spp = 96, 64, 4
+    scene = S.parity_cases(pkg)["knot"]
+    g = np.load(os.path.join(GOLDEN, "rays_knot.npz"))
+    reps = 20
+    org, dir_ = np.tile(g["org"], (reps, 1)), np.tile(g["dir"], (reps, 1))
+    want_prim, want_t = np.tile(g["prim"], reps), np.tile(g["t"], reps)
+
+    def answers():
+        ctx.upload(scene)                       # the node order is applied at upload
+        t, prim, _ = ctx.intersect(org, dir_)
+        ctx.film_bind(W, H)
+        ctx.render(0, spp, spp, seed=21)
+        return t, prim, ctx.film_download()
+
+    _, _, film0 = answers()
+    defaults = {pkg.OPT_TUNE_LDS_SLOTS: 26, pkg.OPT_TUNE_REFILL_IDLE: 44, pkg.OPT_TUNE_EXTEND_BLOCKS: 8,
+                pkg.OPT_TUNE_XCD_GROUP: 0, pkg.OPT_NODE_LAYOUT: 1}
+    cases = [(pkg.OPT_TUNE_LDS_SLOTS, 4), (pkg.OPT_TUNE_LDS_SLOTS, 2), (pkg.OPT_TUNE_REFILL_IDLE, 1),
+             (pkg.OPT_TUNE_REFILL_IDLE, 64), (pkg.OPT_TUNE_EXTEND_BLOCKS, 1), (pkg.OPT_TUNE_XCD_GROUP, 1),
+             (pkg.OPT_NODE_LAYOUT, 0)]
+    try:
+        for opt, value in cases:
+            ctx.set_option(opt, value)
+            t, prim, film = answers()
+            ctx.set_option(opt, defaults[opt])
+            assert np.array_equal(prim, want_prim), "option %d = %d: primitive ids" % (opt, value)
+            assert np.array_equal(t, want_t), "option %d = %d: hit distances" % (opt, value)
+            assert np.array_equal(film, film0), "option %d = %d: film" % (opt, value)
+    finally:
+        for opt, value in defaults.items():
+            ctx.set_option(opt, value)
+
+
 def test_primary_rays_bit_exact(pkg, ctx):
     """generate stage: same counter-based random numbers, same arithmetic -> identical camera rays (thin lens on)."""
     for W, H in [(48, 32), (50, 30)]:         # tiled and untiled pixel enumeration
