@@ -117,7 +117,9 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> res0((size_t)blocks * 256), res1(res0.size());
     printf("active lanes %u of 64, %d blocks per CU, L1 set %u %%, L2 set %u %%, rest from a 64 MB set\n", active, per_cu, p1, p2);
-    for (int mode = 0; mode < 3; mode++) {
+    // the quad modes need every lane of a quad: they are run with all 64 lanes only
+    const int modes = active == 64 ? 3 : 1;
+    for (int mode = 0; mode < modes; mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, steps, out, active, t1, t2);
@@ -131,6 +133,7 @@ int main(int argc, char **argv)
         }
         if (mode < 2) CHECK(hipMemcpy(mode == 0 ? res0.data() : res1.data(), out, res0.size() * 4, hipMemcpyDeviceToHost));
     }
+    if (modes == 1) return 0;
     size_t bad = 0;
     for (size_t i = 0; i < res0.size(); i++) bad += res0[i] != res1[i];
     printf("mode 1 vs mode 0: %zu of %zu lanes differ\n", bad, res0.size());
