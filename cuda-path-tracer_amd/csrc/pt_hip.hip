@@ -912,8 +912,9 @@ static int lane_begin(pt_ctx *ctx, Lane &ln, uint64_t first, uint64_t count, flo
     // (k+1)/n of its slots in its first iteration (the rest follow in the second, which refills the free slots anyway),
     // so that from the start one lane traverses while another generates.  Measured on the headline scene: a 64-spp share
     // 32.0 -> 30.8 ms, 128 spp 61.4 -> 59.2, the 512-spp frame 233 -> 230.6.  Which iteration starts a sample does not
-    // change its slab entry.
-    {
+    // change its slab entry.  A scene without a tree has no extend launches to interleave with: all slots at once.
+    ln.first_take = ln.P;
+    if (ctx->sc.has_bvh) {
         const int k = (int)(&ln - &ctx->lanes[0]);
         ln.first_take = std::max<uint32_t>(1024u, (uint32_t)((uint64_t)ln.P * (k + 1) / nlanes));
     }
