@@ -201,7 +201,7 @@ def test_render_matches_oracle(pkg, ctx, name):
     assert rmse <= 0.25 * rmse_noise, "tone-mapped RMSE %g vs noise %g" % (rmse, rmse_noise)
 
 
-# The two BASELINE.json configurations with a mesh and an .hdr map, loaded from their scene files exactly as the benchmark
+# The two benchmark configurations with a mesh and an .hdr map, loaded from their scene files exactly as the benchmark
 # and the command line load them: reference scene/dragon.scene (868,352-triangle stand-in for the unshipped dragon.obj,
 # forest.hdr stand-in) and scene/bunny.scene (the shipped bunny.obj, sunset.hdr stand-in with a small sun disc of radiance
 # 5e3, the case where the light-sampling pdf of reference src/render.cu:145-151 is most extreme).
@@ -743,7 +743,7 @@ def test_full_size_frame_properties(pkg, ctx):
 
 
 def test_more_than_2_to_32_paths_in_one_call(pkg, ctx):
-    """The largest BASELINE configuration has 8.5 G camera paths (3840x2160x1024): path and ray counters are 64-bit, and a
+    """The largest benchmark configuration has 8.5 G camera paths (3840x2160x1024): path and ray counters are 64-bit, and a
     call whose samples exceed the slab budget runs slab after slab.  Here 3840x2160x520 = 4.31 G paths (> 2^32) of the
     spheres-only scene in one call: every path started exactly once, and the film equal to a 40-sample render of the same
     scene within the noise of 40 samples."""
@@ -766,7 +766,7 @@ def test_more_than_2_to_32_paths_in_one_call(pkg, ctx):
 
 
 def test_hundred_million_triangle_scene_matches_oracle(pkg, ctx):
-    """The largest tree of the BASELINE list at its full size: 116 copies of the 868,352-triangle stand-in in ONE BVH
+    """The largest tree of the benchmark configurations at its full size: 116 copies of the 868,352-triangle stand-in in ONE BVH
     (100.7 M triangles, 9.6 GB of records on the device, glossy and glass meshes alternating, glass spheres between
     them).  The tree is deeper than the traversal stack's LDS column, so part of every deep ray's stack lives in global
     memory.  Hits bit-equal to the oracle on primary + bounced + axis-parallel rays; a small film inside the stated bar."""
