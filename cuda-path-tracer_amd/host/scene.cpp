@@ -84,6 +84,8 @@ int obj_load(const std::string &path, std::vector<float> &verts, uint64_t &ntris
                 char *e = q;
                 const float c = q < eol ? std::strtof(q, &e) : 0.0f;
                 if (e == q || e > eol) return set_error("%s: vertex record with fewer than 3 coordinates", path.c_str());
+                // an infinite or NaN coordinate would poison every box above it in the tree
+                if (!std::isfinite(c)) return set_error("%s: vertex coordinate is not a finite number", path.c_str());
                 pos.push_back(c);
                 q = e;
             }
@@ -111,6 +113,7 @@ int obj_load(const std::string &path, std::vector<float> &verts, uint64_t &ntris
                     }
                 }
             }
+            if (have < 3) return set_error("%s: face record with fewer than 3 vertices", path.c_str());
         }
         p = eol + 1;
     }
@@ -328,7 +331,7 @@ int pth_obj_load(const char *path, float **out_verts, uint64_t *out_ntris)
     if (rc != 0) return rc;
     float *p = (float *)std::malloc(std::max<size_t>(1, v.size()) * sizeof(float));
     if (!p) return set_error("pth_obj_load: out of memory");
-    std::memcpy(p, v.data(), v.size() * sizeof(float));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(float));
     *out_verts = p;
     *out_ntris = n;
     return 0;

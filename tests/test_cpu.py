@@ -457,3 +457,14 @@ def test_obj_vertex_record_must_hold_three_coordinates(pkg, tmp_path):
         pkg.obj_load(str(path))
     path.write_text("v 0 0 0\nv 1 0 0   \nv 0 1 0\r\nf 1 2 3\n")
     assert pkg.obj_load(str(path)).shape == (1, 3, 3)
+    # a face needs three corners, a coordinate has to be a finite number, an index has to name a vertex read so far
+    for text, msg in [("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2\n", "fewer than 3 vertices"),
+                      ("v 0 0 0\nv nan 0 0\nv 0 1 0\nf 1 2 3\n", "not a finite number"),
+                      ("v 0 0 0\nv 1e999 0 0\nv 0 1 0\nf 1 2 3\n", "not a finite number"),
+                      ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n", "out of range"),
+                      ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 -7\n", "out of range")]:
+        path.write_text(text)
+        with pytest.raises(pkg.PtError, match=msg):
+            pkg.obj_load(str(path))
+    path.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3")          # no newline at the end of the file
+    assert pkg.obj_load(str(path)).shape == (1, 3, 3)
