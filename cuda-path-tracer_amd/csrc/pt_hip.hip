@@ -773,7 +773,19 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    free_scene(ctx);
+    // The new scene is built beside the one in place: a scene refused further down (malformed tree, tables out of range,
+    // no memory) leaves the context as it was; only a complete upload replaces and frees the previous scene.
+    struct Replace {
+        pt_ctx *ctx;
+        std::vector<void *> previous;
+        bool complete = false;
+        explicit Replace(pt_ctx *c) : ctx(c) { previous.swap(c->scene_allocs); }
+        ~Replace()
+        {
+            if (!complete) ctx->scene_allocs.swap(previous);        // drop what this call allocated, keep the old scene
+            for (void *p : previous) (void)hipFree(p);
+        }
+    } replace(ctx);
     DScene sc{};
 
     // ---- mesh: re-lay the reference's node + float4-run buffers into one array of 64 B records --------------------
@@ -992,6 +1004,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
     sc.cam = s->camera;
     ctx->sc = sc;
     ctx->have_scene = true;
+    replace.complete = true;
     return PT_OK;
 }
 

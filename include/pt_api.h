@@ -160,7 +160,9 @@ int  pt_set_option(pt_ctx *ctx, int option, uint64_t value);
 
 /* Replaces the cudaMalloc/cudaMemcpy half of Scene::Scene, BVH::send_to_device and
  * EnvironmentMap::send_to_device (reference src/scene.cu:160-214, src/bvh.cu:296-313,
- * src/environment_map.cu:131-134,142-166). */
+ * src/environment_map.cu:131-134,142-166).  A scene that is refused (unknown material type, malformed BVH buffers,
+ * table entries out of range, no memory: negative return, pt_last_error says what) leaves the context with the scene it
+ * had; a complete upload replaces and frees that one. */
 int  pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *scene);
 
 /* Closest hit on a batch of rays given as host arrays of n*3 floats: the body of intersect_scene

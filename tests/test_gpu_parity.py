@@ -703,12 +703,17 @@ def test_upload_rejects_malformed_bvh_buffers(pkg):
     def cycle(b):
         b["nodes"].view(np.int32)[n_nodes - 1, 12] = 1    # a deep node points back up: not a tree
 
+    ray = (np.array([[0, 1, 6]], np.float32), np.array([[0, -0.16, -1]], np.float32))
+    t0, prim0 = c.intersect(*ray)[:2]
     for edit in (child_out_of_range, leaf_past_the_buffer, run_without_terminator, cycle):
         with pytest.raises(pkg.PtError):
             upload(broken(edit))
-    upload(good)                                          # and the context still works afterwards
-    t, prim = c.intersect(np.array([[0, 1, 6]], np.float32), np.array([[0, -0.16, -1]], np.float32))[:2]
-    assert t.shape == (1,)
+        # a refused scene leaves the one in place untouched
+        t, prim = c.intersect(*ray)[:2]
+        assert np.array_equal(t, t0) and np.array_equal(prim, prim0)
+    upload(good)                                          # and the context still takes a good one afterwards
+    t, prim = c.intersect(*ray)[:2]
+    assert np.array_equal(t, t0) and np.array_equal(prim, prim0)
     c.close()
 
 
