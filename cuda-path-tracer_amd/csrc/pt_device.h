@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include "pt_api.h"
+#include "pt_math.h"
 
 namespace ptd {
 
@@ -277,8 +278,8 @@ __device__ __forceinline__ float4 env_fetch(const DScene &sc, float phi, float t
 // reference src/environment_map.cuh:32-37,51-56
 __device__ __forceinline__ float4 env_lookup(const DScene &sc, f3 dir)
 {
-    float phi = __fmaf_rn(atan2f(dir.z, dir.x), 0.5f / kPi, 0.5f);
-    float theta = acosf(clamp1(dir.y)) / kPi;
+    float phi = __fmaf_rn(ptm::atan2_fixed(dir.z, dir.x), 0.5f / kPi, 0.5f);
+    float theta = ptm::acos_fixed(clamp1(dir.y)) / kPi;
     return env_fetch(sc, phi, theta);
 }
 
@@ -296,10 +297,9 @@ __device__ __forceinline__ f3 env_sample_lights(const DScene &sc, Rng &rng)
     uint32_t y = sc.cond[(size_t)x * H + i2];
     float phi = 2.0f * (float)x * kPi / (float)W;
     float theta = (float)y * kPi / (float)H;
-    // sincosf shares the argument reduction and returns what sinf and cosf return
     float st, ct, sp, cp;
-    sincosf(theta, &st, &ct);
-    sincosf(phi, &sp, &cp);
+    ptm::sincos_turn(theta, &st, &ct);
+    ptm::sincos_turn(phi, &sp, &cp);
     float sin_t = -st;
     return {sin_t * cp, -ct, sin_t * sp};
 }
@@ -312,7 +312,7 @@ __device__ __forceinline__ f3 diffuse_dir(f3 n, Rng &rng)
     float a = rng.next() * 2.0f * kPi;
     float r = sqrtf(__fmaf_rn(-z, z, 1.0f));
     float sa, ca;
-    sincosf(a, &sa, &ca);
+    ptm::sincos_turn(a, &sa, &ca);
     float x = r * ca;
     float y = r * sa;
     f3 dir = mk3(x, y, z) + n;
@@ -335,7 +335,7 @@ __device__ __forceinline__ float schlick(float cos_t, float ref_idx)
 {
     float r0 = (1 - ref_idx) / (1 + ref_idx);
     r0 = r0 * r0;
-    return __fmaf_rn(1 - r0, powf(1 - cos_t, 5.0f), r0);
+    return __fmaf_rn(1 - r0, ptm::pow5(1 - cos_t), r0);
 }
 
 // ---- camera -------------------------------------------------------------------------------------------------------

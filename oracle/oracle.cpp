@@ -301,11 +301,77 @@ inline void env_fetch(const orc_scene_desc *sc, float phi, float theta, float ou
     }
 }
 
+// ---- transcendental functions with a fixed operation sequence ------------------------------------------------
+// The reference calls the CUDA math library's sinf / cosf / atan2f / acosf / powf (src/material.cuh:13-21,34-39,
+// src/environment_map.cuh:32-49); its roundings cannot be had here, and the C library's are not the device's either.
+// Both sides therefore evaluate the same single-precision Cephes kernels (sinf/cosf, atanf, asinf) over correctly
+// rounded operations only, so that every random decision of a path comes out the same on the host and on the device.
+// This is the oracle's own statement of them; the device's is csrc/pt_math.h.
+inline void sincos_turn(float x, float *s, float *c)        // x in [0, 2 pi]
+{
+    const float pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f;
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, pio2_hi, x);
+    r = fmaf(-k, pio2_lo, r);
+    const float z = r * r;
+    float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(z, sp, -1.6666654611e-1f);
+    const float sn = fmaf(r * z, sp, r);
+    float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(z, cp, 4.166664568298827e-2f);
+    const float cs = fmaf(z * z, cp, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)k & 3;
+    const float s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    *s = (q & 2) ? -s0 : s0;
+    *c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+inline float atan2_fixed(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const float a = mx > 0.0f ? mn / mx : 0.0f;
+    const bool upper = a > 0.4142135679721832275390625f;
+    const float t = upper ? (a - 1.0f) / (a + 1.0f) : a;
+    const float z = t * t;
+    float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+    p = fmaf(z, p, 1.99777106478e-1f);
+    p = fmaf(z, p, -3.33329491539e-1f);
+    float r = fmaf(t * z, p, t);
+    if (upper) r += 0.785398185253143310546875f;
+    if (ay > ax) r = 1.57079637050628662109375f - r;
+    if (x < 0.0f) r = 3.1415927410125732421875f - r;
+    return y < 0.0f ? -r : r;
+}
+
+inline float asin_half(float x)
+{
+    const float z = x * x;
+    float p = fmaf(z, 4.2163199048e-2f, 2.4181311049e-2f);
+    p = fmaf(z, p, 4.5470025998e-2f);
+    p = fmaf(z, p, 7.4953002686e-2f);
+    p = fmaf(z, p, 1.6666752422e-1f);
+    return fmaf(x * z, p, x);
+}
+
+inline float acos_fixed(float x)                              // x in [-1, 1]
+{
+    if (x > 0.5f) return 2.0f * asin_half(sqrtf(fmaf(-0.5f, x, 0.5f)));
+    if (x < -0.5f) return 3.1415927410125732421875f - 2.0f * asin_half(sqrtf(fmaf(0.5f, x, 0.5f)));
+    return 1.57079637050628662109375f - asin_half(x);
+}
+
+inline float pow5(float x)
+{
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+
 // reference src/environment_map.cuh:32-37,51-56 (acos argument clamped: the reference leaves |y|>1 undefined)
 inline void env_lookup(const orc_scene_desc *sc, V3 dir, float out[4])
 {
-    float phi = fmaf(atan2f(dir.z, dir.x), 0.5f / kPi, 0.5f);
-    float theta = acosf(clamp1(dir.y)) / kPi;
+    float phi = fmaf(atan2_fixed(dir.z, dir.x), 0.5f / kPi, 0.5f);
+    float theta = acos_fixed(clamp1(dir.y)) / kPi;
     env_fetch(sc, phi, theta, out);
 }
 
@@ -323,8 +389,11 @@ inline V3 env_sample_lights(const orc_scene_desc *sc, Rng &rng)
     uint64_t y = sc->env_conditional[x * H + i2];
     float phi = 2.0f * (float)x * kPi / (float)W;
     float theta = (float)y * kPi / (float)H;
-    float sin_t = -sinf(theta);
-    return {sin_t * cosf(phi), -cosf(theta), sin_t * sinf(phi)};
+    float st, ct, sp, cp;
+    sincos_turn(theta, &st, &ct);
+    sincos_turn(phi, &sp, &cp);
+    float sin_t = -st;
+    return {sin_t * cp, -ct, sin_t * sp};
 }
 
 // ---- materials ---------------------------------------------------------------------------------------------
@@ -334,8 +403,10 @@ inline V3 diffuse_dir(V3 n, Rng &rng)
     float z = fmaf(rng.next(), 2.0f, -1.0f);
     float a = rng.next() * 2.0f * kPi;
     float r = sqrtf(fmaf(-z, z, 1.0f));
-    float x = r * cosf(a);
-    float y = r * sinf(a);
+    float sa, ca;
+    sincos_turn(a, &sa, &ca);
+    float x = r * ca;
+    float y = r * sa;
     V3 dir = v3(x, y, z) + n;
     if (dir.x < kEps && dir.y < kEps && dir.z < kEps) return n;
     return normalize3(dir);
@@ -356,7 +427,7 @@ inline float schlick(float cos_t, float ref_idx)
 {
     float r0 = (1 - ref_idx) / (1 + ref_idx);
     r0 = r0 * r0;
-    return fmaf(1 - r0, powf(1 - cos_t, 5.0f), r0);
+    return fmaf(1 - r0, pow5(1 - cos_t), r0);
 }
 
 // reference src/camera.cuh:39-53 and src/render.cu:114-123
@@ -906,6 +977,18 @@ void orc_rgbe_to_float(const uint8_t *rgbe, uint64_t npixels, float *out)
             o[0] = o[1] = o[2] = 0;
         }
         o[3] = 1;
+    }
+}
+
+void orc_math(int which, uint64_t n, const float *a, const float *b, float *out0, float *out1)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        switch (which) {
+        case 0: sincos_turn(a[i], &out0[i], &out1[i]); break;
+        case 1: out0[i] = atan2_fixed(a[i], b[i]); break;
+        case 2: out0[i] = acos_fixed(a[i]); break;
+        default: out0[i] = pow5(a[i]); break;
+        }
     }
 }
 

@@ -16,6 +16,9 @@
  * independent float64 brute force; (4) the RGBE pixel decode against the
  * reference's own vendored reader (stb_image, compiled from the reference
  * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz).
+ * sin / cos / atan2 / acos / x^5 of the shading path are evaluated by fixed polynomial kernels (stated here and,
+ * separately, in the device code) instead of a math library's, so that host and device take every random decision
+ * alike; their error against double precision is held to 3 ulp by the tests.
  * Everything else on the device side
  * (visit order details, shading, environment lookup) is "parity unpinned":
  * the reference ships no tests, fixtures or golden outputs for it and cannot
@@ -153,6 +156,11 @@ void orc_tonemap16(const float *film, uint64_t npixels, float exposure, float ga
 
 /* Radiance RGBE pixel -> float, as stb_image's stbi__hdr_convert does (reference include/stb_image.h:6930-6955). */
 void orc_rgbe_to_float(const uint8_t *rgbe, uint64_t npixels, float *out_rgba);
+
+/* The shading path's transcendental functions (fixed polynomial kernels, see oracle.cpp), for checking their error:
+ * which = 0 sin and cos of a[i] in [0, 2 pi] -> out0, out1; 1 atan2(a[i], b[i]) -> out0; 2 acos(a[i]) -> out0;
+ * 3 a[i]^5 -> out0. */
+void orc_math(int which, uint64_t n, const float *a, const float *b, float *out0, float *out1);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,8 @@ def lib():
                              C.c_uint64, C.c_void_p, C.c_int, C.POINTER(Stats)]
     L.orc_tonemap16.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_float, C.c_void_p]
     L.orc_rgbe_to_float.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    L.orc_math.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_math.restype = None
     _lib = L
     return L
 
@@ -184,3 +186,12 @@ def tonemap16(film, exposure=2.0, gamma=2.2):
     out = np.zeros(film.shape, dtype=np.uint16)
     lib().orc_tonemap16(ptr(film), film.size // 3, exposure, gamma, ptr(out))
     return out
+
+
+def math(which, a, b=None):
+    """The shading path's fixed transcendental kernels: 0 sincos (two results), 1 atan2(a, b), 2 acos, 3 a^5."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out0, out1 = np.zeros_like(a), np.zeros_like(a)
+    lib().orc_math(which, a.size, ptr(a), ptr(b), ptr(out0), ptr(out1))
+    return (out0, out1) if which == 0 else out0

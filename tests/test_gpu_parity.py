@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the frozen fixtures.
 
 Bars: primitive ids bit-exact; hit distance t within 1e-5 relative (the tests in fact demand bit equality, which the
-fixed fma sequence delivers, of the hit normals too); camera rays bit-exact; films within the tolerances stated at each test.
+fixed fma sequence delivers, of the hit normals too); camera rays bit-exact; films bit-exact (same random numbers, same operation sequence, see assert_same_film).
 """
 import ctypes as C
 import os
@@ -56,7 +56,7 @@ def test_intersect_matches_oracle_on_shipped_meshes(pkg, ctx, mesh, cam):
 
 def test_instanced_stress_scene_matches_oracle(pkg, ctx):
     """The 8-GPU stress configuration in small: 9 copies of the 9,216-triangle knot flattened into one glossy mesh with
-    glass spheres between them.  Hits bit-equal to the oracle on primary + bounced rays, film within the stated bar."""
+    glass spheres between them.  Hits and film bit-equal to the oracle."""
     W, H, spp = 128, 72, 4
     scene, ntris = S.instanced_scene(pkg, W, H, 9, base="knot_small.obj")
     assert ntris == 9 * 9216 and scene.desc.num_spheres == 4
@@ -71,8 +71,7 @@ def test_instanced_stress_scene_matches_oracle(pkg, ctx):
     ctx.render(0, spp, spp, seed=4)
     film = ctx.film_download()
     ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=4)
-    _, differing = film_metrics(film, ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+    assert_same_film(film, ofilm, "instanced")
 
 
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
@@ -163,16 +162,16 @@ def film_metrics(a, b):
     return rel_mse, differing
 
 
-# Film tolerance against the oracle at equal spp and equal seed.  Both sides draw the same random numbers, so a pixel
-# differs only through ulp-level differences between the device's and libm's sin/cos/atan2/acos/pow
-# (about 1e-5 relative), except where such a difference flips a discrete decision of one path (a
-# silhouette hit on a sub-pixel triangle, a Russian-roulette or lobe choice) and that path's whole contribution changes.
-# Measured on MI355X: about 0.07 % of the paths (0.54 % of the pixels at 8 spp, 0.17 % at 2 spp).  Stated bar: the
-# share of pixels differing by more than 1e-3 relative is at most 0.2 % per sample per pixel, and the relMSE against
-# the oracle is below 5 % of the Monte-Carlo noise floor (relMSE between two oracle renders that differ only in seed;
-# measured ratios 0.0003 .. 0.01).
-MAX_FLIPPED_PATH_RATE = 0.002
-MAX_RELMSE_OVER_NOISE = 0.05
+# Film bar against the oracle at equal spp and equal seed: BIT EQUALITY, and equal ray counts.  Both sides draw the same
+# counter-based random numbers, execute the same fma sequence and evaluate sin / cos / atan2 / acos / x^5 with the same
+# fixed polynomial kernels (csrc/pt_math.h; the oracle states them separately), and the slab is summed in sample order
+# as the oracle accumulates: every path takes the same decisions and contributes the same floats.  (With a math
+# library's transcendentals, whose last place differs between device and host, about 0.07 % of the paths used to flip a
+# discrete decision.)  Against the reference's own renders the bar is statistical, see test_converged_render_matches_oracle.
+def assert_same_film(film, ofilm, what=""):
+    differing = (film.view(np.uint32) != ofilm.view(np.uint32)).any(axis=2)
+    assert not differing.any(), "%s: %d of %d pixels differ from the oracle in some bit (max abs %g)" % (
+        what, int(differing.sum()), differing.size, float(np.abs(film - ofilm).max()))
 
 
 @pytest.mark.parametrize("name", ["knot", "balls", "city"])
@@ -188,17 +187,10 @@ def test_render_matches_oracle(pkg, ctx, name):
     film = ctx.film_download()
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
     assert st.paths == W * H * spp == ost.paths
-    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
-    rel_mse, differing = film_metrics(film, ofilm)
-    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
-    floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
-    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
-    # tone-mapped 16-bit images: RMSE below a quarter of the seed-to-seed RMSE at this sample count
-    tm = lambda f: pkg.tonemap16(f).astype(np.float64) / 65535
-    rmse = np.sqrt(np.mean((tm(film) - tm(ofilm)) ** 2))
-    rmse_noise = np.sqrt(np.mean((tm(ofilm2) - tm(ofilm)) ** 2))
-    assert rmse <= 0.25 * rmse_noise, "tone-mapped RMSE %g vs noise %g" % (rmse, rmse_noise)
+    assert st.rays == ost.rays
+    assert_same_film(film, ofilm, name)
+    # and the 16-bit image a user sees: identical through the host tone map
+    assert np.array_equal(pkg.tonemap16(film), pkg.tonemap16(ofilm))
 
 
 # The two benchmark configurations with a mesh and an .hdr map, loaded from their scene files exactly as the benchmark
@@ -220,19 +212,15 @@ def test_benchmark_scene_files_match_oracle(pkg, ctx, name):
     assert np.array_equal(t, ot)
     assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32)), "hit normals differ from the oracle's in some bit"
     assert (prim != O.PRIM_MISS).mean() > 0.3
-    # (b) a small render against the oracle, same bars as test_render_matches_oracle
+    # (b) a small render against the oracle: bit-equal
     ctx.film_bind(W, H)
     st = ctx.render(0, spp, spp, seed=5)
     film = ctx.film_download()
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
     assert st.paths == W * H * spp == ost.paths
-    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
+    assert st.rays == ost.rays
     assert np.isfinite(ofilm).all() and np.isfinite(film).all() and (film >= 0).all()
-    rel_mse, differing = film_metrics(film, ofilm)
-    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
-    floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
-    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
+    assert_same_film(film, ofilm, name)
 
 
 @pytest.mark.parametrize("name", ["dragon", "bunny"])
@@ -263,7 +251,7 @@ def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
 
 def test_scene_with_two_meshes_matches_oracle(pkg, ctx):
     """Two OBJ blocks with different materials (Lambertian bunny, glass suzanne) in one BVH: hits bit-equal to the oracle,
-    the film inside the usual bars, and the per-mesh material visibly in effect (the same triangles with one material
+    the film bit-equal too, and the per-mesh material visibly in effect (the same triangles with one material
     for all give another film)."""
     W, H, spp = 96, 64, 8
     scene = pkg.HostScene(S.scene_file(pkg, "two_meshes"), W, H)
@@ -280,12 +268,8 @@ def test_scene_with_two_meshes_matches_oracle(pkg, ctx):
     st = ctx.render(0, spp, spp, seed=5)
     film = ctx.film_download()
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
-    assert abs(int(st.rays) - int(ost.rays)) <= 0.002 * ost.rays
-    rel_mse, differing = film_metrics(film, ofilm)
-    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=6)
-    floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
-    assert rel_mse <= MAX_RELMSE_OVER_NOISE * floor, "relMSE %g vs noise floor %g" % (rel_mse, floor)
+    assert st.rays == ost.rays
+    assert_same_film(film, ofilm, "two meshes")
     # the same buffers as ONE mesh (the first material for every triangle): a different image
     one = pkg.SceneDesc.from_buffer_copy(scene.desc)
     one.meshes, one.num_meshes = None, 0
@@ -305,7 +289,7 @@ def test_scene_with_two_meshes_matches_oracle(pkg, ctx):
 
 
 def test_render_matches_frozen_film(pkg, ctx):
-    """Same bar as above against the film frozen in tests/golden/film_knot.npz (no oracle run involved)."""
+    """Bit equality with the oracle film frozen in tests/golden/film_knot.npz (no oracle run involved)."""
     g = np.load(os.path.join(GOLDEN, "film_knot.npz"))
     W, H, spp, seed = int(g["width"]), int(g["height"]), int(g["spp"]), int(g["seed"])
     scene = S.knot_scene(pkg, W, H)
@@ -313,15 +297,15 @@ def test_render_matches_frozen_film(pkg, ctx):
     ctx.film_bind(W, H)
     st = ctx.render(0, spp, spp, seed=seed)
     film = ctx.film_download()
-    assert st.paths == int(g["paths"])
-    assert abs(int(st.rays) - int(g["rays"])) <= 0.002 * int(g["rays"])
-    _, differing = film_metrics(film, g["film"])
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+    assert st.paths == int(g["paths"]) and st.rays == int(g["rays"])
+    assert_same_film(film, g["film"], "frozen film")
 
 
 def test_converged_render_matches_oracle(pkg, ctx):
-    """A small frame taken close to convergence (1024 spp): absolute bar on the tone-mapped image,
-    RMSE <= 0.01 of full scale, and relMSE of the linear film <= 1e-3."""
+    """A small frame taken close to convergence (1024 spp).  Against the oracle with the same seed: bit-equal.  Against
+    the oracle with ANOTHER seed -- the situation of a comparison with the reference's own renders, whose random stream
+    (cuRAND) is not ours -- the stated image tolerance: relMSE of the linear film and RMSE of the tone-mapped image at most
+    1.5 times what two oracle renders with different seeds differ by, and the tone-mapped RMSE below 2 % of full scale."""
     W, H, spp = 64, 48, 1024
     scene = S.knot_scene(pkg, W, H)
     ctx.upload(scene)
@@ -329,11 +313,15 @@ def test_converged_render_matches_oracle(pkg, ctx):
     ctx.render(0, spp, spp, seed=2)
     film = ctx.film_download()
     ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2)
-    rel_mse, _ = film_metrics(film, ofilm)
+    assert_same_film(film, ofilm, "1024 spp")
+    other, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=3)
+    third, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=4)
     tm = lambda f: pkg.tonemap16(f).astype(np.float64) / 65535
-    rmse = np.sqrt(np.mean((tm(film) - tm(ofilm)) ** 2))
-    assert rmse <= 0.01, "tone-mapped RMSE %g" % rmse
-    assert rel_mse <= 1e-3, "relMSE %g" % rel_mse
+    rmse = np.sqrt(np.mean((tm(film) - tm(other)) ** 2))
+    rmse_floor = np.sqrt(np.mean((tm(third) - tm(other)) ** 2))
+    rel_mse, floor = film_metrics(film, other)[0], film_metrics(third, other)[0]
+    assert rmse <= 1.5 * rmse_floor and rmse <= 0.02, "tone-mapped RMSE %g, seed to seed %g" % (rmse, rmse_floor)
+    assert rel_mse <= 1.5 * floor, "relMSE %g, seed to seed %g" % (rel_mse, floor)
 
 
 def test_device_tonemap_matches_host(pkg, ctx):
@@ -494,9 +482,8 @@ def test_render_film_size_that_does_not_tile(pkg, ctx):
         ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
     assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=13)
-    assert abs(int(st.rays) - int(ost.rays)) <= 0.004 * ost.rays
-    _, differing = film_metrics(films[0], ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+    assert st.rays == ost.rays
+    assert_same_film(films[0], ofilm, "small pool")
 
 
 def test_packed_environment_texels_change_nothing(pkg):
@@ -662,7 +649,7 @@ def test_error_paths(pkg):
     assert st.paths == 48 * 32
     one = c.film_download()
     o, _ = O.render(S.as_oracle_desc(scene), 48, 32, 2, 1, 4, seed=0)
-    assert film_metrics(one, o)[1] <= MAX_FLIPPED_PATH_RATE * 4
+    assert_same_film(one, o, "sample 2 of 4")
     c.close()
 
 
@@ -740,12 +727,9 @@ def test_full_size_frame_properties(pkg, ctx):
         acc += ctx.film_download()
     assert rays == st.rays
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
-    # and a strip of it against the oracle: the same pixels rendered by the CPU
+    # and against the oracle: the same frame rendered by the CPU, bit for bit
     ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=1, nthreads=16)
-    rel_mse, differing = film_metrics(full, ofilm)
-    ofilm2, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=2, nthreads=16)
-    floor, _ = film_metrics(ofilm2, ofilm)
-    assert differing <= MAX_FLIPPED_PATH_RATE * spp and rel_mse <= MAX_RELMSE_OVER_NOISE * floor, (differing, rel_mse, floor)
+    assert_same_film(full, ofilm, "1920x1080")
 
 
 def test_more_than_2_to_32_paths_in_one_call(pkg, ctx):
@@ -775,7 +759,7 @@ def test_hundred_million_triangle_scene_matches_oracle(pkg, ctx):
     """The largest tree of the benchmark configurations at its full size: 116 copies of the 868,352-triangle stand-in in ONE BVH
     (100.7 M triangles, 9.6 GB of records on the device, glossy and glass meshes alternating, glass spheres between
     them).  The tree is deeper than the traversal stack's LDS column, so part of every deep ray's stack lives in global
-    memory.  Hits bit-equal to the oracle on primary + bounced + axis-parallel rays; a small film inside the stated bar."""
+    memory.  Hits bit-equal to the oracle on primary + bounced + axis-parallel rays; a small film bit-equal too."""
     W, H, spp = 160, 90, 2
     try:
         scene, ntris = S.instanced_scene(pkg, W, H, 116)
@@ -793,7 +777,6 @@ def test_hundred_million_triangle_scene_matches_oracle(pkg, ctx):
         film = ctx.film_download()
         ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=12)
         assert np.isfinite(film).all() and (film >= 0).all()
-        _, differing = film_metrics(film, ofilm)
-        assert differing <= MAX_FLIPPED_PATH_RATE * spp, "%.4f of the pixels differ" % differing
+        assert_same_film(film, ofilm, "100.7 M triangles")
     finally:
         S._INSTANCED.clear()                      # 10 GB of host buffers
