@@ -180,6 +180,29 @@ file_name {city}
 """,
 }
 
+# reference scene/suzanne.scene: a pinhole camera (aperture 0), a plane facing +z behind the mesh
+SCENE_TEXT["suzanne"] = """CAMERA
+position 0 -0.05 4
+look_at 0 -0.05 0
+fov 35
+aperture 0
+focus_dist 3.5
+
+ENVIRONMENT
+file_name {studio}
+
+PLANE
+material_type LAMBERTIAN
+albedo 0.06 0.12 0.25
+position 0 0 -0.86
+normal 0 0 1
+
+OBJ
+material_type LAMBERTIAN
+albedo 0.2 0.89 0.915
+file_name {suzanne}
+"""
+
 # two OBJ blocks with different materials (a superset of the reference's one-OBJ scenes): the shipped low-poly bunny,
 # Lambertian, and the shipped suzanne moved to its side, glass
 SCENE_TEXT["two_meshes"] = """CAMERA
@@ -217,7 +240,7 @@ radius 0.5
 """
 
 _SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"],
-                 "city": ["studio.hdr"], "two_meshes": ["studio.hdr"]}
+                 "city": ["studio.hdr"], "two_meshes": ["studio.hdr"], "suzanne": ["studio.hdr"]}
 
 
 def scene_file(pkg, name):
@@ -225,7 +248,7 @@ def scene_file(pkg, name):
     paths = {}
     for kind in _SCENE_ASSETS[name]:
         paths[kind.split(".")[0]] = ensure_asset(pkg, kind)
-    if name in ("bunny", "city"):
+    if name in ("bunny", "city", "suzanne"):
         paths[name] = ensure_mesh_obj(name)
     if name == "two_meshes":
         paths["bunny_lowpoly"] = ensure_mesh_obj("bunny_lowpoly")

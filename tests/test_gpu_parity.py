@@ -132,8 +132,9 @@ def test_traversal_tuning_changes_no_answer(pkg, ctx):
 
 def test_primary_rays_bit_exact(pkg, ctx):
     """generate stage: same counter-based random numbers, same arithmetic -> identical camera rays (thin lens on)."""
-    for W, H in [(48, 32), (50, 30)]:         # tiled and untiled pixel enumeration
-        scene = S.spheres_scene(pkg, W, H)
+    for W, H, pinhole in [(48, 32, False), (50, 30, False), (48, 32, True)]:      # tiled and untiled pixel enumeration
+        # reference scene/suzanne.scene has aperture 0: the pinhole branch of src/camera.cuh:41-44
+        scene = pkg.HostScene(S.scene_file(pkg, "suzanne"), W, H) if pinhole else S.spheres_scene(pkg, W, H)
         ctx.upload(scene)
         for sample in (0, 5):
             org, dir_ = ctx.primary_rays(W, H, sample=sample, seed=99)
@@ -174,11 +175,11 @@ def assert_same_film(film, ofilm, what=""):
         what, int(differing.sum()), differing.size, float(np.abs(film - ofilm).max()))
 
 
-@pytest.mark.parametrize("name", ["knot", "balls", "city"])
+@pytest.mark.parametrize("name", ["knot", "balls", "city", "suzanne"])
 def test_render_matches_oracle(pkg, ctx, name):
     W, H, spp = 96, 64, 8
-    if name == "city":                               # reference scene/city.scene with the shipped mesh
-        scene = pkg.HostScene(S.scene_file(pkg, "city"), W, H)
+    if name in ("city", "suzanne"):                  # reference scene/city.scene, scene/suzanne.scene with the shipped meshes
+        scene = pkg.HostScene(S.scene_file(pkg, name), W, H)
     else:
         scene = S.knot_scene(pkg, W, H) if name == "knot" else S.spheres_scene(pkg, W, H)
     ctx.upload(scene)

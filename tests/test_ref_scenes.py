@@ -30,11 +30,11 @@ def blocks_of(text):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["balls", "bunny", "dragon", "city"])
+@pytest.mark.parametrize("name", ["balls", "bunny", "dragon", "city", "suzanne"])
 def test_carried_scene_texts_are_the_reference_files(name):
     ref = open(os.path.join(REF_SCENES, name + ".scene")).read()
     names = {"studio": "studio.hdr", "sunset": "sunset.hdr", "forest": "forest.hdr", "bunny": "bunny.obj",
-             "city": "city.obj", "dragon": "dragon.obj"}
+             "city": "city.obj", "dragon": "dragon.obj", "suzanne": "suzanne.obj"}
     mine = S.SCENE_TEXT[name].format(**names)
     assert blocks_of(mine) == blocks_of(ref)
 
