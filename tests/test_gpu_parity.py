@@ -250,6 +250,29 @@ def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
+def test_depth_limit_in_a_hall_of_mirrors(pkg, ctx):
+    """Two facing mirror planes of albedo 1 and a glass sphere between them: Russian roulette never ends a path (its
+    survival probability is the throughput's largest channel, reference src/render.cu:78-86), so almost every path runs
+    into the depth cut of src/render.cu:62 (two increments per bounce: 8 bounces) and contributes through it.  Film and
+    ray count bit-equal to the oracle."""
+    W, H, spp = 80, 48, 6
+    cam = pkg.camera_make((0, 1, 4), (0, 1, 0), 50.0, W / H, 0.05, 4.0)
+    tex, marg, cond = S.small_env(pkg)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (1, 1, 1, 0), pkg.MIRROR),
+              pkg.make_plane((0, 2, 0), (0, -1, 0), (1, 1, 1, 0), pkg.MIRROR)]
+    spheres = [pkg.make_sphere((0, 1, 0), 0.6, (1, 1, 1, 1.5), pkg.GLASS)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=17)
+    film = ctx.film_download()
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=17)
+    assert st.paths == W * H * spp and st.rays == ost.rays
+    assert st.rays > 7 * st.paths                      # nine rays for a path that reaches the cut
+    assert_same_film(film, ofilm, "hall of mirrors")
+    assert film.mean() > 0.05                          # the cut paths do contribute
+
+
 def test_scene_with_two_meshes_matches_oracle(pkg, ctx):
     """Two OBJ blocks with different materials (Lambertian bunny, glass suzanne) in one BVH: hits bit-equal to the oracle,
     the film bit-equal too, and the per-mesh material visibly in effect (the same triangles with one material
