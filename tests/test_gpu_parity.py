@@ -170,7 +170,8 @@ def film_metrics(a, b):
 # library's transcendentals, whose last place differs between device and host, about 0.07 % of the paths used to flip a
 # discrete decision.)  Against the reference's own renders the bar is statistical, see test_converged_render_matches_oracle.
 def assert_same_film(film, ofilm, what=""):
-    differing = (film.view(np.uint32) != ofilm.view(np.uint32)).any(axis=2)
+    # a NaN (the 0/0 of reference src/render.cu:145-151 when both pdfs vanish) must be a NaN on both sides
+    differing = ((film.view(np.uint32) != ofilm.view(np.uint32)) & ~(np.isnan(film) & np.isnan(ofilm))).any(axis=2)
     assert not differing.any(), "%s: %d of %d pixels differ from the oracle in some bit (max abs %g)" % (
         what, int(differing.sum()), differing.size, float(np.abs(film - ofilm).max()))
 
@@ -530,6 +531,44 @@ def test_packed_environment_texels_change_nothing(pkg):
     c.upload(S.knot_scene(pkg, W, H))
     assert not c.env_is_packed
     c.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 1), (5, 3), (7, 4), (13, 9), (64, 33)])
+def test_environment_maps_of_odd_sizes(pkg, size):
+    """Environment maps whose sides are not multiples of the 4x4 texel tiles of the packed layout, down to a single texel:
+    bilinear footprints wrap around both edges, the tables have one column.  Packed and unpacked texels give the same
+    film, bit-equal to the oracle's."""
+    ew, eh = size
+    W, H, spp = 64, 40, 4
+    rng = np.random.default_rng(ew * 100 + eh)
+    tex = np.zeros((eh, ew, 4), dtype=np.float32)
+    # values a Radiance pixel can hold: three 8-bit mantissas times one power of two per texel
+    mant = rng.integers(0, 256, size=(eh, ew, 3)).astype(np.float32)
+    expo = rng.integers(-6, 3, size=(eh, ew, 1)).astype(np.float32)
+    tex[..., :3] = mant * np.exp2(expo)
+    tex[0, 0, :3] = [200.0, 180.0, 90.0]               # one bright texel for the light sampling to find
+    tex[..., 3] = 1.0
+    marg, cond = pkg.env_build(tex)
+    cam = pkg.camera_make((0, 1, 5), (0, 0.5, 0), 35.0, W / H, 0.1, 4.75)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (0.325, 0.3, 0.35, 0.0), pkg.DIFFUSE)]
+    spheres = [pkg.make_sphere((-0.7, 0.5, 0), 0.5, (0.7, 0.7, 0.7, 0.0), pkg.DIFFUSE),
+               pkg.make_sphere((0.7, 0.5, 0), 0.5, (0.15, 0.25, 0.4, 0.05), pkg.GLOSSY)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres)
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=23)
+    # (a one-row map sends every light sample straight down, where both pdfs of src/render.cu:145-151 vanish on the floor:
+    # the reference's 0/0; the NaN pixels must be the same pixels on both sides)
+    assert np.isfinite(ofilm).all() or eh == 1
+    for pack in (1, 0):
+        c = pkg.Context(0)
+        c.set_option(pkg.OPT_ENV_PACK, pack)
+        c.upload(scene)
+        assert c.env_is_packed == bool(pack)
+        c.film_bind(W, H)
+        st = c.render(0, spp, spp, seed=23)
+        film = c.film_download()
+        c.close()
+        assert st.rays == ost.rays
+        assert_same_film(film, ofilm, "environment %dx%d, packed %d" % (ew, eh, pack))
 
 
 def test_rays_settled_where_they_are_made_are_counted(pkg, ctx):
