@@ -251,6 +251,45 @@ def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
     assert np.allclose(acc, full, rtol=1e-5, atol=1e-6)
 
 
+def test_many_and_coincident_primitives(pkg, ctx):
+    """Planes and spheres are tested in the order given with a shrinking t_max and a strict comparison, so of two
+    coincident primitives the earlier one is hit (reference src/render.cu:25-33).  40 spheres, 3 planes, two coincident
+    pairs with different materials, a camera inside a glass sphere, over a mesh: primitive ids, t and film bit-equal to
+    the oracle."""
+    W, H, spp = 96, 60, 4
+    rng = np.random.default_rng(41)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (0.4, 0.4, 0.4, 0), pkg.DIFFUSE),
+              pkg.make_plane((0, 0, 0), (0, 1, 0), (0.9, 0.9, 0.9, 0), pkg.MIRROR),        # coincident with the first: never hit
+              pkg.make_plane((0, 0, -6), (0, 0.2, 1), (0.5, 0.5, 0.6, 0.05), pkg.GLOSSY)]
+    spheres = [pkg.make_sphere((0, 1.2, 5), 0.8, (1, 1, 1, 1.5), pkg.GLASS)]               # the camera sits inside this one
+    types = [pkg.DIFFUSE, pkg.MIRROR, pkg.GLOSSY, pkg.GLASS]
+    for k in range(38):
+        c = (float(rng.uniform(-4, 4)), float(rng.uniform(0.2, 2.5)), float(rng.uniform(-4, 2)))
+        spheres.append(pkg.make_sphere(c, float(rng.uniform(0.15, 0.5)), (0.8, 0.6, 0.5, 1.4 if k % 4 == 3 else 0.05), types[k % 4]))
+    spheres.append(pkg.make_sphere((1.5, 0.6, 1.0), 0.6, (0.2, 0.8, 0.2, 0), pkg.DIFFUSE))
+    spheres.append(pkg.make_sphere((1.5, 0.6, 1.0), 0.6, (1, 1, 1, 0), pkg.MIRROR))        # coincident with the one before
+    bvh = pkg.bvh_build(S.knot_mesh(pkg))
+    cam = pkg.camera_make((0, 1.2, 5), (0, 0.8, 0), 45.0, W / H, 0.08, 5.0)
+    tex, marg, cond = S.small_env(pkg)
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
+                            mesh_material=(0.6, 0.3, 0.1, 0.0), mesh_material_type=pkg.DIFFUSE)
+    org, dir_ = S.ray_batch(scene, W, H, seed=31)
+    ctx.upload(scene)
+    t, prim, nrm = ctx.intersect(org, dir_, want_normals=True)
+    ot, oprim, onrm, _ = O.intersect(S.as_oracle_desc(scene), org, dir_, want_normals=True)
+    check_hits(t, prim, ot, oprim, "many primitives")
+    assert np.array_equal(t, ot) and np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32))
+    hit_planes = set(int(p & 0x3FFFFFFF) for p in prim[(prim & 0x80000000) != 0] if p != O.PRIM_MISS)
+    hit_spheres = set(int(p & 0x3FFFFFFF) for p in prim[((prim & 0x40000000) != 0) & ((prim & 0x80000000) == 0)])
+    assert 0 in hit_planes and 1 not in hit_planes
+    assert 39 in hit_spheres and 40 not in hit_spheres and len(hit_spheres) > 20
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=31)
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=31)
+    assert st.rays == ost.rays
+    assert_same_film(ctx.film_download(), ofilm, "many primitives")
+
+
 def test_depth_limit_in_a_hall_of_mirrors(pkg, ctx):
     """Two facing mirror planes of albedo 1 and a glass sphere between them: Russian roulette never ends a path (its
     survival probability is the throughput's largest channel, reference src/render.cu:78-86), so almost every path runs
