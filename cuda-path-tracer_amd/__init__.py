@@ -143,6 +143,7 @@ def hip_lib():
         L.pt_intersect_device_noalloc.argtypes = L.pt_intersect_device.argtypes
         L.pt_primary_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p,
                                       C.c_void_p]
+        L.pt_math_eval.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pt_film_bind.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.pt_film_clear.argtypes = [C.c_void_p]
         L.pt_film_download.argtypes = [C.c_void_p, C.c_void_p]
@@ -371,6 +372,15 @@ class Context:
         dir_ = np.zeros((width * height, 3), dtype=np.float32)
         self._check(self._L.pt_primary_rays(self._h, width, height, sample, seed, _ptr(org), _ptr(dir_)))
         return org, dir_
+
+    def math_eval(self, which, a, b=None):
+        """The device's evaluation of the shading path's transcendental kernels: 0 sincos (two results), 1 atan2(a, b),
+        2 acos, 3 a^5."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+        out0, out1 = np.zeros_like(a), np.zeros_like(a)
+        self._check(self._L.pt_math_eval(self._h, which, a.size, _ptr(a), _ptr(b), _ptr(out0), _ptr(out1)))
+        return (out0, out1) if which == 0 else out0
 
     def film_bind(self, width, height, device_ptr=None):
         self._check(self._L.pt_film_bind(self._h, width, height, device_ptr))

@@ -1177,6 +1177,30 @@ int pt_primary_rays(pt_ctx *ctx, uint32_t W, uint32_t H, uint64_t sample, uint64
     return PT_OK;
 }
 
+int pt_math_eval(pt_ctx *ctx, int which, uint64_t n, const float *a, const float *b, float *out0, float *out1)
+{
+    if (!ctx) return PT_ERR_ARG;
+    if (which < 0 || which > 3 || n > (1ull << 28) || (n && (!a || !out0)) || (which == 1 && n && !b) || (which == 0 && n && !out1))
+        return fail(ctx, PT_ERR_ARG, "pt_math_eval: bad argument");
+    if (n == 0) return PT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *d = nullptr;                                   // a, b, out0, out1 back to back
+    HIPCHK(ctx, hipMalloc(&d, 4 * n * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(d, a, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, which == 1 ? b : a, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_math_eval, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, which, (uint32_t)n, d, d + n,
+                           d + 2 * n, d + 3 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out0, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && which == 0) e = hipMemcpyAsync(out1, d + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_math_eval: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
 int pt_film_bind(pt_ctx *ctx, uint32_t W, uint32_t H, void *device_film)
 {
     if (!ctx) return PT_ERR_ARG;

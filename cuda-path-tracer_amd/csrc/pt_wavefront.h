@@ -566,5 +566,21 @@ __global__ __launch_bounds__(kBlock) void k_primary(DScene sc, uint32_t W, uint3
     }
 }
 
+// the shading path's transcendental kernels (pt_math.h) as the device evaluates them, for parity checks
+__global__ __launch_bounds__(kBlock) void k_math_eval(int which, uint32_t n, const float *__restrict__ a,
+                                                      const float *__restrict__ b, float *__restrict__ out0,
+                                                      float *__restrict__ out1)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        float r0 = 0.0f, r1 = 0.0f;
+        if (which == 0) ptm::sincos_turn(a[i], &r0, &r1);
+        else if (which == 1) r0 = ptm::atan2_fixed(a[i], b[i]);
+        else if (which == 2) r0 = ptm::acos_fixed(a[i]);
+        else r0 = ptm::pow5(a[i]);
+        out0[i] = r0;
+        out1[i] = r1;
+    }
+}
+
 }   // namespace
 }   // namespace ptd

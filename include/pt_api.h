@@ -190,6 +190,12 @@ int  pt_intersect_device_noalloc(pt_ctx *ctx, uint64_t n, const void *d_org4, co
 int  pt_primary_rays(pt_ctx *ctx, uint32_t width, uint32_t height, uint64_t sample, uint64_t seed,
                      float *org_out, float *dir_out);
 
+/* The shading path's transcendental functions as the DEVICE evaluates them, on host arrays of n floats, for parity checks:
+ * which = 0 sin and cos of a[i] in [0, 2 pi] -> out0, out1; 1 atan2(a[i], b[i]) -> out0; 2 acos(a[i]), a in [-1, 1] -> out0;
+ * 3 a[i]^5 -> out0.  They stand where the reference calls the CUDA math library (src/material.cuh:13-21,34-39,
+ * src/environment_map.cuh:32-49) and are fixed polynomial kernels whose bits do not depend on where they run. */
+int  pt_math_eval(pt_ctx *ctx, int which, uint64_t n, const float *a, const float *b, float *out0, float *out1);
+
 /* The film: float3[width*height], row 0 = top (reference Scene::image_data, src/scene.cu:216, src/render.cu:121).
  * device_film = NULL lets the library allocate it; otherwise the caller's device buffer is accumulated into
  * (e.g. a tensor that is reduced across GPUs afterwards). */

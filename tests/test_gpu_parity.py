@@ -143,6 +143,28 @@ def test_primary_rays_bit_exact(pkg, ctx):
             assert np.array_equal(dir_, odir)
 
 
+def test_device_evaluates_the_transcendental_kernels_to_the_oracles_bits(pkg, ctx):
+    """sin / cos / atan2 / acos / x^5 as the device evaluates them against the oracle's statement of the same kernels, on
+    millions of inputs over and beyond the ranges the path tracer feeds them (signed zeros, the axes, the ends of the
+    intervals included): every result the same bits."""
+    rng = np.random.default_rng(19)
+
+    def same(x, y):
+        return np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+    turn = np.concatenate([rng.uniform(0, 2 * np.pi, 2000000), np.linspace(0, 6.2831855, 500001),
+                           np.arange(0, 2049) * (2 * np.pi / 2048), np.arange(0, 1025) * (np.pi / 1024)]).astype(np.float32)
+    (s0, c0), (s1, c1) = ctx.math_eval(0, turn), O.math(0, turn)
+    assert same(s0, s1) and same(c0, c1)
+    y, x = rng.normal(size=2000000).astype(np.float32), rng.normal(size=2000000).astype(np.float32)
+    y[:10], x[:10] = [0, 0, 1, -1, 0, -0.0, 1e-30, -1e-30, 1e38, 3], [1, -1, 0, 0, 0, -0.0, 1e30, -1e30, 1e38, 3]
+    assert same(ctx.math_eval(1, y, x), O.math(1, y, x))
+    unit = np.concatenate([rng.uniform(-1, 1, 2000000), np.linspace(-1, 1, 500001), 1 - np.geomspace(1e-7, 1, 5000),
+                           [-1, 1, 0, -0.0, 0.5, -0.5]]).astype(np.float32)
+    assert same(ctx.math_eval(2, unit), O.math(2, unit))
+    assert same(ctx.math_eval(3, unit), O.math(3, unit))
+
+
 def test_empty_and_single_ray(pkg, ctx):
     scene = S.spheres_scene(pkg, 48, 32)
     ctx.upload(scene)
