@@ -3,6 +3,8 @@
 //   mode 1  the four lanes of a quad load one record together, 16 B each (one 64 B segment per quad and load), four loads
 //           cover the quad's four records, then a 4x4 transpose inside the quad gives every lane its record
 //   mode 2  as mode 1 without the transpose (upper bound of what the load side can gain; results meaningless)
+//   mode 3  structure of arrays: the record's four 16 B parts live in four arrays (part c of record i at c * records + i),
+//           so a lane's four loads go to four different cache lines
 // Every lane walks a pseudo-random chain: next index = hash(sum of the record's words) so loads depend on each other.
 // usage: gather_probe [records] [steps] [lds_bytes_per_block] [active_lanes]
 // active_lanes < 64 (mode 0 only): the other lanes of every wave sit out (exec-masked), as lanes without a ray do in the
@@ -67,6 +69,8 @@ __global__ __launch_bounds__(256) void k_probe(const float4 *__restrict__ recs, 
         if (MODE == 0) {
             const float4 *p = recs + (size_t)idx * 4;
             r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+        } else if (MODE == 3) {
+            r[0] = recs[idx]; r[1] = recs[(size_t)nrec + idx]; r[2] = recs[2 * (size_t)nrec + idx]; r[3] = recs[3 * (size_t)nrec + idx];
         } else {
             const uint32_t j = lane & 3u;
             // quad_perm [q,q,q,q]: the index held by lane q of the quad
@@ -114,12 +118,13 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<uint32_t> res0((size_t)blocks * 256), res1(res0.size());
-    for (int mode = 0; mode < (active < 64 ? 1 : 3); mode++) {
+    for (int mode = 0; mode < (active < 64 ? 1 : 4); mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
+            if (mode == 3) hipLaunchKernelGGL(k_probe<3>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
