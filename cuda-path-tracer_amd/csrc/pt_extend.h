@@ -21,15 +21,8 @@ namespace ptd {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
-// PT_KCHUNK / PT_STEPS: compile-time overrides for A/B builds (tools/ab_libs.sh)
-#ifndef PT_KCHUNK
-#define PT_KCHUNK 128
-#endif
-#ifndef PT_STEPS
-#define PT_STEPS 2
-#endif
-constexpr int kStepsPerCheck = PT_STEPS;
-constexpr uint32_t kChunk = PT_KCHUNK;           // rays per chunk; chunk c belongs to wave c mod #waves
+constexpr int kStepsPerCheck = 2;                // traversal steps between two looks at the refill condition
+constexpr uint32_t kChunk = 128;                 // rays per chunk; chunk c belongs to wave c mod #waves
 // stream kernel: refill once this many lanes have no ray.  Measured on the 868 k-triangle stand-in, 78 M rays per launch
 // (ms per frame): 8 -> 356, 16 -> 342, 24 -> 333, 32 -> 327, 44 -> 320, 56 -> 340.  Idle lanes cost no memory traffic,
 // which is what bounds the kernel; every refill is issue time the wave's live rays stand still for.
@@ -56,14 +49,14 @@ struct RayState {
     float t;
     uint32_t hid;
     int node, sp;
-    int top0, top1;            // PT_REGTOP: the two topmost stack entries (top0 above top1), see stack_push
+    f3 hn;                     // un-normalised normal of the triangle hit (kept only by kernels that shade, KEEPN)
     uint32_t c_nodes, c_tris, c_leaves;
 };
 
-// A lane's traversal stack: slot s lives at lds[s * kBlock] (a column of the block's LDS array) while s < lds_slots and,
+// A lane's traversal stack: slot s lives at lds[s * BLOCK] (a column of the block's LDS array) while s < lds_slots and,
 // in kernels built with OVERFLOW, in a global array beyond that.  Trees shallow enough for LDS alone use the kernels
-// without the overflow test.
-template <bool OVERFLOW>
+// without the overflow test.  BLOCK = threads per block of the kernel that owns the array.
+template <bool OVERFLOW, int BLOCK = kBlock>
 struct Stack {
     int *lds;
     int *glob;
@@ -71,59 +64,40 @@ struct Stack {
     uint32_t gstride;
     __device__ __forceinline__ void put(int slot, int v) const
     {
-        if (!OVERFLOW || slot < lds_slots) lds[slot * kBlock] = v;
+        if (!OVERFLOW || slot < lds_slots) lds[slot * BLOCK] = v;
         else __builtin_nontemporal_store(v, glob + (size_t)(slot - lds_slots) * gstride);
     }
     __device__ __forceinline__ int get(int slot) const
     {
-        if (!OVERFLOW || slot < lds_slots) return lds[slot * kBlock];
+        if (!OVERFLOW || slot < lds_slots) return lds[slot * BLOCK];
         return __builtin_nontemporal_load(glob + (size_t)(slot - lds_slots) * gstride);
     }
 };
 
-template <bool OVERFLOW>
-__device__ __forceinline__ Stack<OVERFLOW> make_stack(int *lds_base, const ExtendArgs &a)
+template <bool OVERFLOW, int BLOCK = kBlock>
+__device__ __forceinline__ Stack<OVERFLOW, BLOCK> make_stack(int *lds_base, int lds_slots, int *gstk)
 {
-    Stack<OVERFLOW> s;
+    Stack<OVERFLOW, BLOCK> s;
     s.lds = lds_base + threadIdx.x;
-    s.gstride = gridDim.x * kBlock;
-    s.glob = OVERFLOW ? a.gstk + (blockIdx.x * kBlock + threadIdx.x) : nullptr;
-    s.lds_slots = a.lds_slots;
+    s.gstride = gridDim.x * BLOCK;
+    s.glob = OVERFLOW ? gstk + (blockIdx.x * BLOCK + threadIdx.x) : nullptr;
+    s.lds_slots = lds_slots;
     return s;
 }
 
-// The traversal stack of a ray.  Default: all entries in the lane's LDS column, R.sp = entries on the stack.
-// PT_REGTOP (compile-time, for A/B builds): the two topmost entries live in registers (R.top0 above R.top1) and only the
-// entries below them in the LDS column, which then needs two slots fewer; a pop hands out a register at once and refills
-// the lower register from LDS behind it.  Measured on MI355X (868 k-triangle stand-in, 1920x1080x512): 244.8 ms per frame
-// against 241.4 with the pure LDS column; the shifts cost 17 % more vector instructions and the two slots buy no block.
-#ifndef PT_REGTOP
-#define PT_REGTOP 0
-#endif
-constexpr int kRegTop = PT_REGTOP ? 2 : 0;
-
+// The traversal stack of a ray: all entries in the lane's column, R.sp = entries on the stack; the bottom entry is the
+// sentinel whose pop ends the traversal.
 template <class STK>
 __device__ __forceinline__ void stack_reset(RayState &R, const STK &stk)
 {
-    if (PT_REGTOP) {
-        R.top0 = kSentinel;                 // bottom entry: popping it ends the traversal
-        R.top1 = kSentinel;
-    } else {
-        stk.put(0, kSentinel);
-    }
+    stk.put(0, kSentinel);
     R.sp = 1;
 }
 
 template <class STK>
 __device__ __forceinline__ void stack_push(RayState &R, const STK &stk, int v)
 {
-    if (PT_REGTOP) {
-        if (R.sp >= 2) stk.put(R.sp - 2, R.top1);
-        R.top1 = R.top0;
-        R.top0 = v;
-    } else {
-        stk.put(R.sp, v);
-    }
+    stk.put(R.sp, v);
     R.sp++;
 }
 
@@ -131,12 +105,6 @@ template <class STK>
 __device__ __forceinline__ int stack_pop(RayState &R, const STK &stk)
 {
     R.sp--;
-    if (PT_REGTOP) {
-        const int v = R.top0;
-        R.top0 = R.top1;
-        if (R.sp >= 2) R.top1 = stk.get(R.sp - 2);
-        return v;
-    }
     return stk.get(R.sp);
 }
 
@@ -244,7 +212,7 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
 
 // One triangle step (reference src/bvh.cuh:171-187, 93-120): test the record, go on to the next record of the leaf or
 // pop after the last one.
-template <bool COUNT, class STK>
+template <bool COUNT, bool KEEPN, class STK>
 __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const STK &stk, float4 v00, float4 v11, float4 v22,
                                          float4 meta)
 {
@@ -265,6 +233,7 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
         if ((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f)) {
             R.t = t;
             R.hid = (uint32_t)R.node;
+            if (KEEPN) R.hn = cross3(xyz(v11), xyz(v22));      // reference src/bvh.cuh:114
         }
     }
     int next = R.node + 1;
@@ -296,7 +265,7 @@ __device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, c
         }
         while (R.node != kSentinel && (uint32_t)R.node >= sc.first_tri) {
             const float4 *p = sc.recs + (size_t)R.node * 4;
-            tri_step<COUNT>(sc, R, stk, p[0], p[1], p[2], p[3]);
+            tri_step<COUNT, false>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
     }
 }
@@ -306,7 +275,7 @@ extern __shared__ int g_stack_lds[];      // [lds_slots][kBlock], sized at launc
 template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a)
 {
-    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
+    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a.lds_slots, a.gstk);
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
     const uint32_t stride = gridDim.x * kBlock;
     RayState R;
@@ -322,9 +291,11 @@ __global__ __launch_bounds__(kBlock) void k_extend_batch(DScene sc, ExtendArgs a
 }
 
 // ---- persistent single-step traversal ---------------------------------------------------------------------------------
-template <bool COUNT, bool CANON, class STK>
-__device__ __forceinline__ void record_step(const DScene &sc, RayState &R, const STK &stk)
+// One step of a lane that has a ray: fetch the 64 B record the ray stands at, then an inner-node or a triangle step.
+template <bool COUNT, bool CANON, bool KEEPN, class STK>
+__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
+    if (R.node == kSentinel) return;
     const float4 *p = sc.recs + (size_t)R.node * 4;
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     float4 r3 = p[3];
@@ -332,16 +303,7 @@ __device__ __forceinline__ void record_step(const DScene &sc, RayState &R, const
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
     if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
-    else tri_step<COUNT>(sc, R, stk, r0, r1, r2, r3);
-#ifdef PT_VALU_PAD
-    // sensitivity probe: PT_VALU_PAD extra vector instructions per step that change nothing
-    {
-        float pad = R.t;
-#pragma unroll
-        for (int k = 0; k < PT_VALU_PAD; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(pad));
-        asm volatile("" ::"v"(pad));
-    }
-#endif
+    else tri_step<COUNT, KEEPN>(sc, R, stk, r0, r1, r2, r3);
     // Keep the record address in registers of its own until the step is over.  When the allocator lets it share
     // registers with one of the four loaded values, the next step's address computation has to wait for every
     // outstanding memory operation first (s_waitcnt vmcnt(0)) -- the streaming stores of rays retired at the last
@@ -349,28 +311,10 @@ __device__ __forceinline__ void record_step(const DScene &sc, RayState &R, const
     asm volatile("" ::"v"(p));
 }
 
-// One step of every lane that has a ray.
-// PT_CHAIN (compile-time, off): a second, chained step for the lanes whose next record is the other half of the 128 B line
-// the step has just fetched (an even record index followed by that index + 1: a node and the child placed beside it at
-// upload, or the second triangle of a leaf).  That record is in the L1 by then, but the extra round trip in every
-// iteration costs more than the steps it saves: measured on MI355X, 868 k-triangle stand-in, 306.3 ms per frame against
-// 277.5 without it (one stream), 271.7 against 240.7 (three streams); hits identical.
-#ifndef PT_CHAIN
-#define PT_CHAIN 0
-#endif
-template <bool COUNT, bool CANON, class STK>
-__device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
-{
-    if (R.node == kSentinel) return;
-    const int cur = R.node;
-    record_step<COUNT, CANON>(sc, R, stk);
-    if (PT_CHAIN && R.node == cur + 1 && !(cur & 1)) record_step<COUNT, CANON>(sc, R, stk);
-}
-
 template <bool OVERFLOW, bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs a)
 {
-    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a);
+    const Stack<OVERFLOW> stk = make_stack<OVERFLOW>(g_stack_lds, a.lds_slots, a.gstk);
     const uint32_t n = a.n_ptr ? *a.n_ptr : a.n_fixed;
     // wave-uniform cursor over this wave's chunks of the ray buffer: chunks first, first + step, ... below last
     uint32_t chunk = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
@@ -394,7 +338,6 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
     R.c_nodes = R.c_tris = R.c_leaves = 0;
     R.node = kSentinel;
     R.sp = 1;
-    R.top0 = R.top1 = kSentinel;
     R.t = kFltMax;
     R.hid = PT_PRIM_MISS;
     R.o = R.d = R.inv = R.nood = mk3(0, 0, 0);
@@ -435,14 +378,14 @@ __global__ __launch_bounds__(kBlock) void k_extend_stream(DScene sc, ExtendArgs 
             canon = __any(degenerate);
             if (!__any(ray != kNoRay)) break;            // nothing in flight and nothing left to fetch
         }
-        // kStepsPerCheck traversal steps between two looks at the refill condition (measured 1/2/3/4: 280.6/279.1/279.2/
-        // 280.1 ms per frame)
+        // kStepsPerCheck traversal steps between two looks at the refill condition (measured on MI355X, 1/2/3/4 steps:
+        // 280.6/279.1/279.2/280.1 ms per frame)
         if (canon) {
 #pragma unroll
-            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, true>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, true, false>(sc, R, stk);
         } else {
 #pragma unroll
-            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false>(sc, R, stk);
+            for (int s = 0; s < kStepsPerCheck; s++) stream_step<COUNT, false, false>(sc, R, stk);
         }
     }
     flush_counts<COUNT>(R, a.cnt3);

@@ -22,6 +22,7 @@
 #include "pt_device.h"
 #include "pt_extend.h"
 #include "pt_wavefront.h"
+#include "pt_path.h"
 
 using namespace ptd;
 
@@ -119,6 +120,11 @@ struct pt_ctx {
     bool env_pack = true;      // use the packed environment texels when they are exact
     int xcd_group = 0;         // extend: each XCD's blocks work on one contiguous eighth of the ray buffer
     int node_layout = 1;       // 0: inner nodes in the order given, 1: parent + favoured child share a 128 B line
+    int render_mode = 1;       // 1: wavefront iterations over path buffers, 2: whole paths in one persistent kernel
+    int path_waves = 0;        // k_path_stream: cap on resident waves per CU (0: as many as fit)
+    int path_refill = 44;      // k_path_stream: service once this many lanes wait for it
+    int path_lds_slots = 32;   // k_path_stream: traversal stack slots per lane kept in LDS
+    PathCounters *pcnt = nullptr, *h_pcnt = nullptr;   // k_path_stream's counters, device and pinned host
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
     uint32_t *tmp_hid = nullptr;   // hit ids of the closest-hit entry points
@@ -295,8 +301,8 @@ static int launch_extend(pt_ctx *ctx, hipStream_t stream, Counters *cnt, bool n_
                          size_t *gstk_threads, const float4 *ro, const float4 *rd, uint32_t n_fixed, uint32_t n_upper,
                          uint32_t *hid, float *t)
 {
-    // slots the LDS column has to hold: tree depth + 1, less what the kernel keeps in registers
-    const uint32_t need = ctx->sc.has_bvh ? std::max<uint32_t>(1, ctx->sc.stack_slots - std::min<uint32_t>(kRegTop, ctx->sc.stack_slots - 1)) : 1;
+    // slots the LDS column has to hold: tree depth + 1
+    const uint32_t need = ctx->sc.has_bvh ? std::max<uint32_t>(1, ctx->sc.stack_slots) : 1;
     const int lds_slots = gstk ? (int)std::min<uint32_t>(need, (uint32_t)ctx->lds_slots) : (int)need;
     const bool overflow = need > (uint32_t)lds_slots;
     const int per_cu = std::max(1, std::min(ctx->extend_blocks, 160 / lds_slots));
@@ -596,6 +602,104 @@ static bool node_layout_pairs(const float *nodes, uint64_t N, std::vector<uint32
     return pos == N && newid[0] == 0;
 }
 
+// pt_render with whole paths in one persistent kernel: per slab ONE k_path_stream launch over all its camera paths, then
+// the slab is folded into the film.  Everything is queued on the context's stream; the host waits once per slab for the
+// counters.
+static int render_paths(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint32_t s0, uint32_t s1,
+                        uint64_t slab_samples, pt_stats *stats)
+{
+    const uint32_t W = ctx->W, H = ctx->H, npix = W * H;
+    hipStream_t st = ctx->stream;
+    // traversal stack: tree depth + 1 slots per lane, 256 B of LDS per slot and wave; beyond 40 slots (160 KB / 16 waves)
+    // the rest goes to a global array
+    const uint32_t need = ctx->sc.has_bvh ? std::max<uint32_t>(1, ctx->sc.stack_slots) : 1;
+    const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->path_lds_slots);
+    const bool overflow = need > (uint32_t)lds_slots;
+    const size_t shmem = (size_t)lds_slots * kPathBlock * sizeof(int);
+    const bool count = ctx->count_traversal;
+    const void *kern = overflow ? (count ? (const void *)k_path_stream<true, true> : (const void *)k_path_stream<true, false>)
+                                : (count ? (const void *)k_path_stream<false, true> : (const void *)k_path_stream<false, false>);
+    int per_cu = 0;
+    HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kPathBlock, shmem));
+    if (per_cu < 1) return fail(ctx, PT_ERR_HIP, "pt_render: the path kernel does not fit a CU (%zu B of LDS)", shmem);
+    if (ctx->path_waves > 0) per_cu = std::min(per_cu, ctx->path_waves);
+    if (std::getenv("PT_DEBUG"))
+        std::fprintf(stderr, "[pt] k_path_stream: %d waves per CU, %d stack slots in LDS%s, tree needs %u\n", per_cu, lds_slots,
+                     overflow ? ", overflow to global" : "", need);
+    const uint32_t cps = (npix + kPathChunk - 1) / kPathChunk;
+    if ((uint64_t)cps * slab_samples >= 0xFFFF0000ull) return fail(ctx, PT_ERR_ARG, "pt_render: sample slab too large");
+    pt_stats acc{};
+    double kernel_ms = 0;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
+    for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
+        const uint64_t first = spp_begin + done_samples;
+        const uint64_t count_s = std::min<uint64_t>(slab_samples, spp_count - done_samples);
+        const uint32_t total_chunks = (uint32_t)(cps * count_s);
+        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu,
+                                                                       ((uint64_t)npix * count_s + kPathBlock - 1) / kPathBlock));
+        if (overflow) {
+            const size_t threads = (size_t)grid * kPathBlock;
+            if (!ctx->gstk || ctx->gstk_threads < threads) {
+                if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; ctx->gstk_threads = 0; }
+                const size_t want = std::max(threads, (size_t)ctx->num_cus * 8 * kBlock);
+                HIPCHK(ctx, hipMalloc(&ctx->gstk, want * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
+                ctx->gstk_threads = want;
+            }
+        }
+        PathArgs a{};
+        a.slab = ctx->slab;
+        a.slab_first_sample = (uint32_t)first;
+        a.W = W; a.H = H; a.npix = npix;
+        a.row_div = make_fastdiv(pixel_divisor(W, H));
+        a.chunks_per_sample = cps;
+        a.cps_div = make_fastdiv(cps);
+        a.total_chunks = total_chunks;
+        a.seed0 = s0; a.seed1 = s1;
+        a.cnt = ctx->pcnt;
+        a.refill_idle = ctx->path_refill;
+        a.lds_slots = lds_slots;
+        a.gstk = ctx->gstk;
+        HIPCHK(ctx, hipMemsetAsync(ctx->pcnt, 0, sizeof(PathCounters), st));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));          // re-used as "kernel begins" (timing enabled below)
+        const dim3 g(grid), b(kPathBlock);
+        if (overflow) {
+            if (count) hipLaunchKernelGGL((k_path_stream<true, true>), g, b, shmem, st, ctx->sc, a);
+            else hipLaunchKernelGGL((k_path_stream<true, false>), g, b, shmem, st, ctx->sc, a);
+        } else {
+            if (count) hipLaunchKernelGGL((k_path_stream<false, true>), g, b, shmem, st, ctx->sc, a);
+            else hipLaunchKernelGGL((k_path_stream<false, false>), g, b, shmem, st, ctx->sc, a);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
+        hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count_s, npix,
+                           (float)spp_total, ctx->film);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pcnt, ctx->pcnt, sizeof(PathCounters), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_slab_free, ctx->ev_end));
+        kernel_ms += ms;
+        const PathCounters &c = *ctx->h_pcnt;
+        acc.rays += c.rays;
+        acc.paths += c.paths;
+        acc.rays_escaped += c.settled;
+        acc.iterations += 1;
+        acc.extend_launches += 1;
+        acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (stats) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+        acc.ms_total = ms;
+        acc.ms_extend = kernel_ms;
+        acc.ms_extend_busy = kernel_ms;
+        *stats = acc;
+    }
+    return PT_OK;
+}
+
 extern "C" {
 
 int pt_ctx_create(int device, pt_ctx **out)
@@ -626,6 +730,8 @@ int pt_ctx_create(int device, pt_ctx **out)
     CREATECHK(scratch_on_device(device, &ctx->scratch));
     CREATECHK(hipMalloc(&ctx->cnt, sizeof(Counters)));
     CREATECHK(hipHostMalloc(&ctx->h_cnt, sizeof(Counters)));
+    CREATECHK(hipMalloc(&ctx->pcnt, sizeof(PathCounters)));
+    CREATECHK(hipHostMalloc(&ctx->h_pcnt, sizeof(PathCounters)));
     for (auto &ln : ctx->lanes) {
         CREATECHK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
         CREATECHK(hipMalloc(&ln.cnt, sizeof(Counters)));
@@ -637,7 +743,7 @@ int pt_ctx_create(int device, pt_ctx **out)
     }
     CREATECHK(hipEventCreate(&ctx->ev_begin));
     CREATECHK(hipEventCreate(&ctx->ev_end));
-    CREATECHK(hipEventCreateWithFlags(&ctx->ev_slab_free, hipEventDisableTiming));
+    CREATECHK(hipEventCreate(&ctx->ev_slab_free));
 #undef CREATECHK
     {
         std::lock_guard<std::mutex> lock(g_rccl_mu);
@@ -673,6 +779,8 @@ void pt_ctx_destroy(pt_ctx *ctx)
     free_scene(ctx);
     if (ctx->film_owned) (void)hipFree(ctx->film);
     (void)hipFree(ctx->cnt);
+    (void)hipFree(ctx->pcnt);
+    if (ctx->h_pcnt) (void)hipHostFree(ctx->h_pcnt);
     (void)hipFree(ctx->gstk);
     (void)hipFree(ctx->tmp_hid);
     (void)hipFree(ctx->stage_o); (void)hipFree(ctx->stage_d); (void)hipFree(ctx->stage_h);
@@ -737,6 +845,22 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
     case PT_OPT_NODE_LAYOUT:
         if (value > 1) return fail(ctx, PT_ERR_ARG, "node layout %llu unknown", (unsigned long long)value);
         ctx->node_layout = (int)value;
+        return PT_OK;
+    case PT_OPT_RENDER_MODE:
+        if (value != 1 && value != 2) return fail(ctx, PT_ERR_ARG, "render mode %llu unknown", (unsigned long long)value);
+        ctx->render_mode = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_PATH_WAVES:
+        if (value > 32) return fail(ctx, PT_ERR_ARG, "path waves per CU %llu out of [0, 32]", (unsigned long long)value);
+        ctx->path_waves = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_PATH_LDS_SLOTS:
+        if (value < 2 || value > 64) return fail(ctx, PT_ERR_ARG, "LDS stack slots %llu out of [2, 64]", (unsigned long long)value);
+        ctx->path_lds_slots = (int)value;
+        return PT_OK;
+    case PT_OPT_TUNE_PATH_REFILL:
+        if (value < 1 || value > 64) return fail(ctx, PT_ERR_ARG, "service threshold %llu out of [1, 64]", (unsigned long long)value);
+        ctx->path_refill = (int)value;
         return PT_OK;
     default: return fail(ctx, PT_ERR_ARG, "unknown option %d", option);
     }
@@ -1345,6 +1469,8 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         }
         ctx->slab_bytes = slab_samples * per_sample;
     }
+
+    if (ctx->render_mode == 2) return render_paths(ctx, spp_begin, spp_count, spp_total, s0, s1, slab_samples, stats);
 
     pt_stats acc{};
     double ext_ms = 0;

@@ -149,6 +149,14 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_NODE_LAYOUT      11  /* 1 (default): inner nodes are re-ordered at upload so that a node and the child a ray most
                                        likely visits next share a 128 B cache line; 0: the order given.  Hits do not depend on
                                        it.  Read by pt_scene_upload. */
+#define PT_OPT_RENDER_MODE      13  /* 2 (default): every camera path is traced from first ray to end by one lane of a persistent
+                                       kernel (traversal steps, logic and shading in the same wave; no path buffers);
+                                       1: wavefront iterations over path buffers (bounce / generate / extend kernels on
+                                       PT_OPT_STREAMS streams).  The film does not depend on it. */
+#define PT_OPT_TUNE_PATH_WAVES  14  /* render mode 2 tuning: cap on resident waves per CU (0 = as many as fit, default) */
+#define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 44) */
+#define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS; deeper entries go to a
+                                       global array */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 

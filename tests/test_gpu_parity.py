@@ -742,6 +742,76 @@ def test_traversal_counters_match_oracle(pkg, ctx):
     assert np.array_equal(hit.cpu().numpy()[:, 3].view(np.uint32), g["prim"])
 
 
+
+def _whole_path_scenes(pkg, W, H):
+    return {
+        "knot": lambda: S.knot_scene(pkg, W, H),                                   # glossy mesh, all four materials around it
+        "balls": lambda: S.spheres_scene(pkg, W, H),                               # no tree: every ray is settled where it is made
+        "two_meshes": lambda: pkg.HostScene(S.scene_file(pkg, "two_meshes"), W, H),   # per-mesh materials
+        "suzanne": lambda: pkg.HostScene(S.scene_file(pkg, "suzanne"), W, H),      # pinhole camera
+    }
+
+
+@pytest.mark.parametrize("name", ["knot", "balls", "two_meshes", "suzanne"])
+def test_whole_path_kernel_matches_oracle(pkg, ctx, name):
+    """PT_OPT_RENDER_MODE 2 (every path traced from its first ray to its end by one lane of a persistent kernel): film, ray
+    count, settled-ray count and traversal counters equal to the oracle's and to the wavefront loop's, also with a traversal
+    stack that overflows into global memory and with a service threshold that keeps waves nearly empty or nearly full."""
+    W, H, spp = 96, 64, 6
+    scene = _whole_path_scenes(pkg, W, H)[name]()
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=21)
+    ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 1)
+    try:
+        wst = ctx.render(0, spp, spp, seed=21)
+        assert_same_film(ctx.film_download(), ofilm, name + " wavefront")
+        ctx.set_option(pkg.OPT_RENDER_MODE, 2)
+        for refill, lds in ((44, 32), (1, 32), (64, 32), (44, 3)):
+            ctx.set_option(pkg.OPT_TUNE_PATH_REFILL, refill)
+            ctx.set_option(pkg.OPT_TUNE_PATH_LDS_SLOTS, lds)
+            ctx.film_clear()
+            st = ctx.render(0, spp, spp, seed=21)
+            what = "%s threshold %d, %d LDS slots" % (name, refill, lds)
+            assert_same_film(ctx.film_download(), ofilm, what)
+            assert st.paths == W * H * spp and st.rays == ost.rays == wst.rays, what
+            assert st.rays_escaped == wst.rays_escaped, what
+            assert (st.nodes, st.tris, st.leaves) == (ost.nodes, ost.tris, ost.leaves) == (wst.nodes, wst.tris, wst.leaves), what
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 1)
+        ctx.set_option(pkg.OPT_TUNE_PATH_REFILL, 44)
+        ctx.set_option(pkg.OPT_TUNE_PATH_LDS_SLOTS, 32)
+        ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 0)
+
+
+def test_whole_path_kernel_slabs_partition_and_odd_sizes(pkg, ctx):
+    """Render mode 2 on a film that does not tile into 8x4 pixel blocks and whose pixel count is not a multiple of the chunk
+    of camera paths a wave claims: one slab, several slabs and a split of the samples over two calls give the oracle's film
+    (the split: up to float addition order)."""
+    W, H, spp = 250, 150, 7
+    scene = S.knot_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=5)
+    ctx.set_option(pkg.OPT_RENDER_MODE, 2)
+    try:
+        st = ctx.render(0, spp, spp, seed=5)
+        assert st.rays == ost.rays
+        assert_same_film(ctx.film_download(), ofilm, "one slab")
+        ctx.set_option(pkg.OPT_SLAB_BYTES, 1 << 20)              # 1 MiB: one sample of this film (600 KB) per slab
+        ctx.film_clear()
+        st = ctx.render(0, spp, spp, seed=5)
+        assert st.rays == ost.rays and st.iterations == spp
+        assert_same_film(ctx.film_download(), ofilm, "several slabs")
+        ctx.film_clear()
+        ctx.render(0, 3, spp, seed=5)
+        ctx.render(3, spp - 3, spp, seed=5)
+        assert np.allclose(ctx.film_download(), ofilm, rtol=1e-5, atol=1e-7)
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 1)
+        ctx.set_option(pkg.OPT_SLAB_BYTES, 32 << 30)
+
+
 def test_error_paths(pkg):
     c = pkg.Context(0)
     with pytest.raises(pkg.PtError):
