@@ -9,15 +9,23 @@ A step is one full frame of the headline workload: the reference's scene/dragon.
 and the float films are summed onto rank 0 with one reduce (RCCL); the reduce is inside the timed region.  Total work
 is fixed, so scaling is "strong".  One ray = one closest-hit query.
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself: N fresh child processes, one
+per GPU, before this process has made any GPU call; rank 0's JSON line is relayed and the exit code is non-zero if any
+rank failed.
+
 The JSON line also carries
-  roofline      the extend (traversal) kernel against the 8 TB/s HBM peak.  achieved = algorithmic bytes per launch (120 B
-                of path state + 64 B per inner node visited + 48 B per triangle tested + 16 B per leaf entered, the
-                per-ray means counted by the CPU oracle on a reduced-resolution run of the same scene, times the rays the
-                launch traces) divided by the mean HIP-event duration of the non-empty extend launches, measured on the
-                library's own streams.  The tree is served by L1/L2/Infinity Cache, so these are not HBM bytes: the block
-                also carries what the counters say (traffic = fabric-side bytes per launch from committed rocprofv3
-                --pmc passes of this command, with cache hit rates and lane utilisation from the same passes) and the
-                kernel's record fetch rate against the rate a bare dependent-gather probe reaches at the same hit mix.
+  roofline      the extend (traversal) kernel against the 8 TB/s HBM peak.  Headline (achieved, frac, traffic): the bytes
+                the kernel really moves on the fabric side of the L2s, from committed rocprofv3 --pmc passes of this very
+                command, over the kernel's run time in the same profile (launches serialised there) -- a figure that cannot
+                exceed the peak.  It is reported only when the profile was taken on the kernel sources being run (a hash
+                of csrc/ ties them); otherwise null.  Beside it, measured live in this run with HIP events on the library's
+                own streams: `algorithmic` = the algorithmic bytes per launch (120 B of path state + 64 B per inner node
+                visited + 48 B per triangle tested + 16 B per leaf entered, per-ray means counted by the CPU oracle on a
+                reduced-resolution run of the same scene, times the rays the launch traces) over the mean duration of the
+                non-empty extend launches.  The tree is served by L1 / L2 / Infinity Cache and launches of several streams
+                overlap, so that figure is NOT an HBM fraction and may exceed the peak; `record_rate` = the 64 B records
+                the launches fetch per second of extend time against the rate a bare dependent-gather probe reaches at the
+                same hit mix and lane occupancy (what really binds the kernel; at most 1).
   cpu_baseline  the CPU oracle (a host restatement of the reference's traversal and shading) timed on this machine's
                 cores on a bounded sample of the same workload (960x540, 320 spp).
   film_check    the film of the last timed frame: finite everywhere, and its mean next to the mean of the oracle's film
@@ -28,24 +36,24 @@ The JSON line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import __graft_entry__ as G  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0
 B_STATE = 120.0
+# committed counter-side profiles of the extend kernel, one per workload they were taken on
+PROFILES = {"dragon": "profiles/r3_extend_traffic.json", "dragon_dense": "profiles/r3_extend_traffic_dragon_dense.json",
+            "synth": "profiles/r3_extend_traffic_synth.json"}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -53,14 +61,74 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=512)
-    ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "balls", "city", "synth"])
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "dragon_dense", "bunny", "balls", "city", "synth"],
+                    help="dragon_dense: the dragon scene with the frame-filling variant of the stand-in mesh (91 %% of the "
+                         "camera rays hit it, 44 inner nodes per ray)")
     ap.add_argument("--instances", type=int, default=116,
                     help="--scene synth: copies of the dragon stand-in flattened into one mesh (116 = 100.7 M triangles)")
     ap.add_argument("--pool", type=int, default=0, help="path slots in flight (0: library default)")
     ap.add_argument("--extend-mode", type=int, default=2, help="2 persistent single-step waves (default), 1 loop-per-phase batches")
     ap.add_argument("--tune", default="", help="comma list of option=value pairs passed to pt_set_option")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """Runs this command as n ranks, one fresh child process each, and returns the exit code for the parent.  Called before
+    the parent has imported torch or touched the GPU: the children are ordinary child processes (nothing is re-executed),
+    each gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them.  Rank 0's
+    standard output (the JSON line) is relayed; the other ranks' goes to standard error."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # Wait for all ranks.  Once one has failed the others cannot finish their collectives: they get 30 s, then they are
+    # ended (by their process ids, which this process owns).
+    codes = [None] * n
+    failed_at = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None and p.poll() is not None:
+                codes[r] = p.returncode
+                if codes[r] != 0 and failed_at is None:
+                    failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()
+                    codes[r] = p.wait()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    failed = any(c != 0 for c in codes)
+    out0 = out0[0] if out0 else b""
+    # the JSON line to standard output, anything else a rank 0 library printed there (gloo does) to standard error
+    for line in out0.decode(errors="replace").splitlines():
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    if failed:
+        print("bench: rank exit codes %r" % (codes,), file=sys.stderr)
+        return 1
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as G
 
     pkg = G.load_package()
     import cuda_path_tracer_amd.distributed as D
@@ -237,17 +305,32 @@ def main():
                              # pixel's bits and the ray count equal to the oracle's
                              "sample_bit_equal_to_oracle": same_bits}
         # Counter-side figures of the extend kernel, from the committed rocprofv3 --pmc passes of this same command (not
-        # collected here: counters need profiler runs of their own); null when absent or for another workload
+        # collected here: counters need profiler runs of their own).  Used only when they were taken on this workload AND
+        # on the kernel sources this run executes; otherwise the counter-side fields are null.
         prof = None
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_extend_traffic.json"))
-        if cands and args.scene == "dragon" and (args.width, args.height, args.spp) == (1920, 1080, 512):
-            prof = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-            prof["file"] = "profiles/" + cands[-1]
-            if b_ray is None:
-                # the oracle's per-ray traversal means of this workload are deterministic; without the CPU leg (N > 1 or
-                # --no-cpu-baseline) the committed figures of the same workload are used
-                b_ray = prof.get("algorithmic_bytes_per_ray")
-                trav = (prof.get("nodes_per_ray"), prof.get("tris_per_ray"))
+        prof_why = "no committed counter profile for this workload"
+        workload = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp}
+        if args.scene == "synth":
+            workload["instances"] = args.instances
+        pfile = PROFILES.get(args.scene)
+        if pfile and os.path.exists(os.path.join(ROOT, pfile)):
+            cand = json.load(open(os.path.join(ROOT, pfile)))
+            if cand.get("workload") != workload:
+                prof_why = "%s was taken on %r" % (pfile, cand.get("workload"))
+            else:
+                if b_ray is None:
+                    # the oracle's per-ray traversal means of this workload are deterministic; without the CPU leg (N > 1
+                    # or --no-cpu-baseline) the committed figures of the same workload are used
+                    b_ray = cand.get("algorithmic_bytes_per_ray")
+                    trav = (cand.get("nodes_per_ray"), cand.get("tris_per_ray"))
+                if cand.get("kernel_source_hash") != G.kernel_source_hash():
+                    prof_why = "%s was taken on other kernel sources (%s, running %s)" % (
+                        pfile, str(cand.get("kernel_source_hash"))[:12], G.kernel_source_hash()[:12])
+                elif args.tune or args.pool or args.extend_mode != 2:
+                    prof_why = "%s was taken with the default options" % pfile
+                else:
+                    prof = cand
+                    prof["file"] = pfile
         if b_ray is not None and acc["ms_extend"] > 0 and acc["launches"] > 0:
             # b_ray is the mean over ALL rays.  Rays that were settled where they were created (one root visit in the
             # oracle's count) never reach an extend launch, so their bytes are taken out of what the launches are credited with.
@@ -256,51 +339,64 @@ def main():
             ext_rays = acc["rays"] - acc["rays_escaped"]
             launches = acc["launches"]
             avg_ms = acc["ms_extend"] / launches
-            achieved = ext_bytes / (acc["ms_extend"] * 1e-3) / 1e9
-            traffic = prof.get("traffic_bytes_per_launch") if (prof and world == 1) else None
+            alg_launch = ext_bytes / (acc["ms_extend"] * 1e-3) / 1e9
+            alg_frame = ext_bytes / elapsed / 1e9
+            counters = prof is not None and world == 1
+            traffic = prof.get("traffic_bytes_per_launch") if counters else None
+            achieved = prof.get("achieved_traffic_gbs") if counters else None
             out["config"]["rays_escaped_at_creation_per_frame"] = int(acc["rays_escaped"] / max(1, args.steps))
             roof = {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # Headline: bytes the kernel moves on the fabric side of the L2s (FETCH_SIZE x 2 + WRITE_SIZE, Infinity-Cache
+                # hits included: an upper estimate of the HBM bytes) per launch, over the launch's duration with the launches
+                # serialised, both from the committed profile of this command on these kernel sources.  Cannot exceed 1.
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_extend_stream",
-                "launches": int(launches),
-                "avg_launch_ms": round(avg_ms, 4),
-                "rays_per_launch": round(ext_rays / launches, 1),
-                "bytes_per_launch": round(ext_bytes / launches, 0),
-                # The library runs several wavefront loops on streams of their own, so extend launches overlap each other
-                # and the other kernels; a launch's duration is then longer than it would be alone.
+                "what_binds": "the rate at which a CU turns around per-lane 64 B record fetches that miss L1 (see record_rate); "
+                              "HBM itself binds only where the tree does not fit the 256 MB Infinity Cache (--scene synth)",
+                "counters_source": prof["file"] if counters else None,
+                "counters_missing_because": None if counters else (prof_why if world == 1 else "N > 1"),
+                # Measured live in this run (HIP events on the library's streams).  NOT an HBM fraction: the algorithmic bytes
+                # are mostly served by L1 / L2 / Infinity Cache, and with several streams a launch's duration includes the
+                # time it shares the GPU with other launches.  May exceed the peak.
+                "algorithmic": {
+                    "bytes_per_ray": round(b_ray, 1),
+                    "launches": int(launches),
+                    "avg_launch_ms": round(avg_ms, 4),
+                    "rays_per_launch": round(ext_rays / launches, 1),
+                    "bytes_per_launch": round(ext_bytes / launches, 0),
+                    "gbs_per_launch": round(alg_launch, 1),
+                    "frac_per_launch": round(alg_launch / HBM_PEAK_GBS, 4),
+                    "gbs_over_frame": round(alg_frame, 1),
+                    "over_frame": round(alg_frame / HBM_PEAK_GBS, 4),
+                    "traffic_over_algorithmic": None if not traffic else round(traffic * launches / ext_bytes, 4),
+                },
                 "concurrent_streams": streams,
                 "extend_busy_share_of_frame": round(acc["ms_extend_busy"] / max(1e-9, acc["ms_render"]), 3),
                 # rays that enter an extend launch (the ones a tree is traversed for) per second of frame time
                 "traversed_mrays_per_s": round(ext_rays / elapsed / 1e6, 1),
             }
             if trav and trav[0] is not None:
-                # 64 B records the launches fetch: every node visit and triangle test of the rays they trace
+                # 64 B records the launches fetch (every node visit and triangle test of the rays they trace) per second of
+                # the time at least one extend launch runs, against a bare dependent-gather loop at extend's own cache-hit
+                # mix and lane occupancy (tools/gather_probe2, figure from the committed profile)
                 recs = (trav[0] + trav[1]) * acc["rays"] - acc["rays_escaped"] * (1.0 if has_tree else 0.0)
-                roof["records_per_s"] = round(recs / (acc["ms_extend_busy"] * 1e-3), 0)
-            if prof:
-                roof["counters"] = {
-                    "source": prof["file"],
-                    # fabric-side bytes per launch over the launch's duration IN THE COUNTER RUN (launches serialised there)
-                    "achieved_traffic": prof.get("achieved_traffic_gbs"),
-                    "frac_traffic": None if prof.get("achieved_traffic_gbs") is None
-                    else round(prof["achieved_traffic_gbs"] / HBM_PEAK_GBS, 4),
-                    "traffic_over_algorithmic": None if not traffic else round(traffic * launches / ext_bytes, 4),
-                    "l2_hit_rate": prof.get("l2_hit_rate"),
-                    "l1_hit_share_of_records": prof.get("l1_hit_share"),
-                    "active_lane_fraction": prof.get("active_lane_fraction"),
-                    "valu_busy": prof.get("valu_busy"),
-                    "waves_waiting": prof.get("waves_waiting"),
-                    # what a bare dependent-gather kernel reaches on this GPU at the same L1 / L2 / fabric mix
-                    "record_rate_ceiling": prof.get("record_rate_ceiling"),
-                    "frac_of_record_rate_ceiling": None if not (prof.get("record_rate_ceiling") and roof.get("records_per_s"))
-                    else round(roof["records_per_s"] / prof["record_rate_ceiling"], 4),
-                    # a bare gather loop at extend's own mix and lane occupancy, and extend's rate when it runs alone
-                    # (one stream, from the same profile run): how much of the memory pipeline's rate the kernel reaches
-                    "probe_at_extend_mix_records_per_s": None if not prof.get("probe_mixed_g_records_per_s")
-                    else prof["probe_mixed_g_records_per_s"] * 1e9,
-                    "extend_alone_records_per_s": prof.get("extend_alone_records_per_s"),
+                rate = recs / (acc["ms_extend_busy"] * 1e-3)
+                ceiling = None if not (counters and prof.get("probe_mixed_g_records_per_s")) else prof["probe_mixed_g_records_per_s"] * 1e9
+                roof["record_rate"] = {
+                    "records_per_s": round(rate, 0),
+                    "probe_at_extend_mix_records_per_s": ceiling,
+                    "frac": None if not ceiling else round(rate / ceiling, 4),
+                    "extend_alone_records_per_s": prof.get("extend_alone_records_per_s") if counters else None,
+                    "extend_alone_frac": None if not (ceiling and prof.get("extend_alone_records_per_s"))
+                    else round(prof["extend_alone_records_per_s"] / ceiling, 4),
                 }
+            if counters:
+                roof["counters"] = {k: prof.get(k) for k in (
+                    "l2_hit_rate", "l1_hit_share", "fabric_share_of_records", "active_lane_fraction", "valu_busy",
+                    "waves_waiting", "ta_busy", "extend_ms_per_frame_one_stream", "kernel_source_hash", "git_commit")}
+            else:
+                roof["counters"] = None
             out["roofline"] = roof
         else:
             out["roofline"] = None

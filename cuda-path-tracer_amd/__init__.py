@@ -22,6 +22,7 @@ OPT_TUNE_EXTEND_BLOCKS = 10
 OPT_NODE_LAYOUT = 11
 OPT_TUNE_XCD_GROUP = 12
 OPT_RENDER_MODE, OPT_TUNE_PATH_WAVES, OPT_TUNE_PATH_REFILL, OPT_TUNE_PATH_LDS_SLOTS = 13, 14, 15, 16
+OPT_NORMAL_TABLE = 17
 
 
 class Plane(C.Structure):
@@ -362,10 +363,12 @@ class Context:
         self._check(self._L.pt_intersect_device(self._h, n, d_org4, d_dir4, d_hit4, d_t, C.byref(st)))
         return st
 
-    def intersect_device_noalloc(self, n, d_org4, d_dir4, d_hit4, d_t):
-        """intersect_device without any device allocation (static scratch, at most 4,194,304 rays).  Returns Stats."""
-        st = Stats()
-        self._check(self._L.pt_intersect_device_noalloc(self._h, n, d_org4, d_dir4, d_hit4, d_t, C.byref(st)))
+    def intersect_device_noalloc(self, n, d_org4, d_dir4, d_hit4, d_t, want_stats=True):
+        """intersect_device without any device allocation (static scratch, at most 4,194,304 rays).  Returns Stats; with
+        want_stats=False the kernels are only queued on the context's stream (no synchronisation) and None is returned."""
+        st = Stats() if want_stats else None
+        self._check(self._L.pt_intersect_device_noalloc(self._h, n, d_org4, d_dir4, d_hit4, d_t,
+                                                        C.byref(st) if want_stats else None))
         return st
 
     def primary_rays(self, width, height, sample=0, seed=0):

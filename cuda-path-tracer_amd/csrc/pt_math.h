@@ -45,7 +45,8 @@ PTM_FN void sincos_turn(float x, float *s, float *c)
     *c = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// atan2(y, x) in [-pi, pi]; (0, 0) gives 0
+// atan2(y, x) in [-pi, pi]; (0, 0) gives 0.  Signs are taken from the sign bits, so the zeros behave as atan2f's do:
+// atan2(-0, x < 0) = -pi, atan2(+-0, -0) = +-pi.
 PTM_FN float atan2_fixed(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
@@ -60,8 +61,8 @@ PTM_FN float atan2_fixed(float y, float x)
     float r = fmaf(t * z, p, t);
     if (upper) r += kPio4;
     if (ay > ax) r = kPio2Hi - r;
-    if (x < 0.0f) r = kPiF - r;
-    return y < 0.0f ? -r : r;
+    if (signbit(x)) r = kPiF - r;
+    return copysignf(r, y);
 }
 
 PTM_FN float asin_half(float x)                              // |x| <= 0.5

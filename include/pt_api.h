@@ -149,14 +149,17 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_NODE_LAYOUT      11  /* 1 (default): inner nodes are re-ordered at upload so that a node and the child a ray most
                                        likely visits next share a 128 B cache line; 0: the order given.  Hits do not depend on
                                        it.  Read by pt_scene_upload. */
-#define PT_OPT_RENDER_MODE      13  /* 2 (default): every camera path is traced from first ray to end by one lane of a persistent
-                                       kernel (traversal steps, logic and shading in the same wave; no path buffers);
-                                       1: wavefront iterations over path buffers (bounce / generate / extend kernels on
-                                       PT_OPT_STREAMS streams).  The film does not depend on it. */
+#define PT_OPT_RENDER_MODE      13  /* 1 (default): wavefront iterations over path buffers (bounce / generate / extend kernels on
+                                       PT_OPT_STREAMS streams); 2: every camera path is traced from first ray to end by one
+                                       lane of a persistent kernel (traversal steps, logic and shading in the same wave; no
+                                       path buffers).  The film does not depend on it. */
 #define PT_OPT_TUNE_PATH_WAVES  14  /* render mode 2 tuning: cap on resident waves per CU (0 = as many as fit, default) */
 #define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 44) */
 #define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS; deeper entries go to a
                                        global array */
+#define PT_OPT_NORMAL_TABLE     17  /* 1 (default): pt_scene_upload also makes a 16 B per triangle table of unit normal + reported
+                                       id, which shading and the closest-hit entry points read instead of gathering the hit
+                                       triangle's 64 B record; 0: no table.  Same bits either way.  Read by pt_scene_upload. */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 
@@ -183,10 +186,16 @@ int  pt_intersect(pt_ctx *ctx, uint64_t n, const float *org, const float *dir,
 int  pt_intersect_device(pt_ctx *ctx, uint64_t n, const void *d_org4, const void *d_dir4,
                          void *d_hit4, void *d_t, pt_stats *stats);
 
-/* pt_intersect_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit, but the
+/* pt_intersect_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc,
+ * code under HIP stream capture).  No counterpart in the reference.  Same arguments, same results bit for bit, but the
  * call makes no hipMalloc / hipFree: its hit-id scratch and counters live in one static device array per GPU (16 MiB +
  * 256 B, held by every GPU the library runs on until the process ends) and its traversal stacks in LDS only.
+ * Two behaviours, chosen by `stats`:
+ *   stats != NULL  synchronous, like pt_intersect_device: counters reset, HIP events around the traversal, the stream
+ *                  waited for, *stats filled.  Not usable while the stream (pt_stream) is being captured.
+ *   stats == NULL  the traversal and the hit-expansion kernel are only QUEUED on the context's stream and the call
+ *                  returns: no memset, no event, no copy, no synchronisation -- nothing a stream capture refuses.  The
+ *                  results are complete once the stream has passed that point.
  * Limits: n <= 4,194,304 rays per call and a tree of at most 47 levels (48 stack slots); beyond either the call returns
  * PT_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race, whatever their
  * contexts or streams. */

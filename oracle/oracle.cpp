@@ -340,8 +340,9 @@ inline float atan2_fixed(float y, float x)
     float r = fmaf(t * z, p, t);
     if (upper) r += 0.785398185253143310546875f;
     if (ay > ax) r = 1.57079637050628662109375f - r;
-    if (x < 0.0f) r = 3.1415927410125732421875f - r;
-    return y < 0.0f ? -r : r;
+    // signs by sign bit, so that the zeros behave as atan2f's: atan2(-0, x < 0) = -pi, atan2(+-0, -0) = +-pi
+    if (std::signbit(x)) r = 3.1415927410125732421875f - r;
+    return std::signbit(y) ? -r : r;
 }
 
 inline float asin_half(float x)

@@ -180,6 +180,10 @@ file_name {city}
 """,
 }
 
+# the dragon scene with the frame-filling variant of the stand-in mesh (91 % of the camera rays hit it, 44 inner nodes per
+# ray): the traversal-bound workload
+SCENE_TEXT["dragon_dense"] = SCENE_TEXT["dragon"].replace("{dragon}", "{dragon_dense}")
+
 # reference scene/suzanne.scene: a pinhole camera (aperture 0), a plane facing +z behind the mesh
 SCENE_TEXT["suzanne"] = """CAMERA
 position 0 -0.05 4
@@ -240,7 +244,7 @@ radius 0.5
 """
 
 _SCENE_ASSETS = {"balls": ["studio.hdr"], "bunny": ["sunset.hdr"], "dragon": ["forest.hdr", "dragon.obj"],
-                 "city": ["studio.hdr"], "two_meshes": ["studio.hdr"], "suzanne": ["studio.hdr"]}
+                 "dragon_dense": ["forest.hdr", "dragon_dense.obj"], "city": ["studio.hdr"], "two_meshes": ["studio.hdr"], "suzanne": ["studio.hdr"]}
 
 
 def scene_file(pkg, name):
@@ -391,6 +395,68 @@ def spheres_scene(pkg, width, height):
         pkg.make_sphere((2.025, 0.5, 0), 0.5, (0.15, 0.25, 0.4, 0.05), pkg.GLOSSY),
     ]
     return pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres)
+
+
+def chain_scene(pkg, levels, width=48, height=32):
+    """A degenerate BVH of `levels` inner nodes in a chain, written by hand in the reference's buffer layout
+    (src/bvh.cu:36-41, 224-226, 275-277): node i has the one-triangle leaf of triangle i on the left and the rest of the
+    chain on the right (the last node has two leaves).  Triangle i is a slab at x = i, so a ray travelling towards -x from
+    beyond the last triangle finds the rest-of-chain box nearer at every node, pushes the leaf and descends: its traversal
+    stack grows to the full depth of the tree.  Woop rows come from the product's builder (a throw-away tree over the
+    same triangles)."""
+    K = levels + 1
+    tris = np.zeros((K, 3, 3), dtype=np.float32)
+    for k in range(K):
+        tris[k] = [[k, -1.0 - 0.01 * k, -1.0], [k, 1.0, -1.0 - 0.01 * k], [k, 0.0, 1.0 + 0.01 * k]]
+    ref = pkg.bvh_build(tris)
+    # prim_ids names a triangle at the float4 index of its first row only: keep the smallest index per triangle
+    first_row = {}
+    a = 1
+    while a < ref["num_tri_float4"]:
+        if ref["tris"][a].view(np.uint32)[0] == 0x80000000:
+            a += 1
+            continue
+        first_row[int(ref["prim_ids"][a])] = a
+        a += 3
+    assert sorted(first_row) == list(range(K))
+    buf = np.zeros((1 + 4 * K + 2, 4), dtype=np.float32)
+    ids = np.zeros(1 + 4 * K, dtype=np.uint32)
+    for k in range(K):
+        at = 1 + 4 * k
+        buf[at:at + 3] = ref["tris"][first_row[k]:first_row[k] + 3]
+        buf[at + 3].view(np.uint32)[:] = 0x80000000
+        ids[at] = k
+    lo = tris.min(axis=1) - np.float32(0.001)
+    hi = tris.max(axis=1) + np.float32(0.001)
+    nodes = np.zeros((levels, 16), dtype=np.float32)
+    for i in range(levels):
+        rlo, rhi = lo[i + 1:].min(axis=0), hi[i + 1:].max(axis=0)
+        nodes[i, 0:4] = [lo[i, 0], hi[i, 0], lo[i, 1], hi[i, 1]]
+        nodes[i, 4:8] = [rlo[0], rhi[0], rlo[1], rhi[1]]
+        nodes[i, 8:12] = [lo[i, 2], hi[i, 2], rlo[2], rhi[2]]
+        ch = nodes[i].view(np.int32)
+        ch[12] = ~np.int32(1 + 4 * i)
+        ch[13] = i + 1 if i + 1 < levels else ~np.int32(1 + 4 * (i + 1))
+    bvh = {"nodes": nodes, "tris": buf, "prim_ids": ids, "num_tri_float4": 1 + 4 * K, "num_tris": K}
+    cam = pkg.camera_make((K + 3.0, 0.2, 0.3), (0, 0, 0), 30.0, width / height, 0.0, 4.0)
+    tex, marg, cond = small_env(pkg)
+    return pkg.ManualScene(cam, tex, marg, cond, bvh=bvh, mesh_material=(0.6, 0.6, 0.6, 0.0),
+                           mesh_material_type=pkg.DIFFUSE)
+
+
+def chain_rays(levels, n=4096, seed=0):
+    """Rays along the chain in both directions (the -x ones fill the stack), slightly off axis."""
+    rng = np.random.default_rng(seed)
+    K = levels + 1
+    org = np.zeros((n, 3), dtype=np.float32)
+    d = np.zeros((n, 3), dtype=np.float32)
+    back = rng.random(n) < 0.7
+    org[:, 0] = np.where(back, K + 2.0, -2.0)
+    org[:, 1:] = rng.uniform(-0.3, 0.3, size=(n, 2))
+    d[:, 0] = np.where(back, -1.0, 1.0)
+    d[:, 1:] = rng.uniform(-0.02, 0.02, size=(n, 2))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return org, d.astype(np.float32)
 
 
 def as_oracle_desc(scene):

@@ -397,6 +397,25 @@ def test_two_rank_film_reduce_gloo(tmp_path):
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (no WORLD_SIZE) starts two rank processes itself, before it has
+    touched a GPU, and reports their failure with a non-zero exit code instead of hanging.  On a machine without a GPU both
+    ranks come up, rendezvous over gloo on 127.0.0.1 and then stop at the device ("No HIP GPUs"); on a GPU box the
+    rehearsal form of the same command renders (tests/test_gpu_parity.py)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank exit codes [1, 1]" in r.stderr
+    assert "[rank0]" in r.stderr and "[rank1]" in r.stderr          # both ranks ran, each under its own RANK
+    assert "No HIP GPUs" in r.stderr
+    assert r.stdout.strip() == ""
+
+
 def test_oracle_film_matches_frozen_fixture(pkg):
     """The oracle's film of the knot scene equals the frozen one (tests/golden/film_knot.npz, written by
     tools/make_golden_film.py): scene construction, shading restatement and random streams have not drifted.
@@ -495,9 +514,12 @@ def test_fixed_transcendental_kernels_are_accurate():
     want = np.arctan2(y.astype(np.float64), xx.astype(np.float64))
     assert np.abs(a[8:] - want[8:]).max() < 4e-7               # |atan2| <= pi: 1.7 ulp at pi
     assert ulp_error(a[8:], want[8:]).max() <= 3.0
-    # the axes and the origin: (0, 0) gives 0 whatever the zeros' signs
+    # the axes and the origin, with the zeros' signs treated as atan2f treats them: atan2(0, 0) = 0, atan2(0, -0) = pi
     assert a[0] == 0 and abs(a[1] - np.pi) < 3e-7 and abs(a[2] - np.pi / 2) < 2e-7 and abs(a[3] + np.pi / 2) < 2e-7
-    assert a[4] == 0 and a[5] == 0 and abs(a[6]) < 1e-37 and abs(abs(a[7]) - np.pi) < 3e-7
+    assert a[4] == 0 and abs(a[5] - np.pi) < 3e-7 and abs(a[6]) < 1e-37 and abs(a[7] + np.pi) < 3e-7
+    # signed zeros: the sign of y decides the sign of the result, -0 included (atan2f(-0, x < 0) = -pi)
+    z = O.math(1, np.array([-0.0, -0.0, 0.0, -0.0], np.float32), np.array([-1.0, 1.0, -0.0, -0.0], np.float32))
+    assert abs(z[0] + np.pi) < 3e-7 and z[1] == 0 and np.signbit(z[1]) and abs(z[2] - np.pi) < 3e-7 and abs(z[3] + np.pi) < 3e-7
     v = np.concatenate([np.linspace(-1, 1, 400001), rng.uniform(-1, 1, 200000), 1 - np.geomspace(1e-7, 1, 2000)]).astype(np.float32)
     ac = O.math(2, v)
     want = np.arccos(v.astype(np.float64))

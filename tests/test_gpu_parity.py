@@ -221,11 +221,12 @@ def test_render_matches_oracle(pkg, ctx, name):
 # and the command line load them: reference scene/dragon.scene (868,352-triangle stand-in for the unshipped dragon.obj,
 # forest.hdr stand-in) and scene/bunny.scene (the shipped bunny.obj, sunset.hdr stand-in with a small sun disc of radiance
 # 5e3, the case where the light-sampling pdf of reference src/render.cu:145-151 is most extreme).
-@pytest.mark.parametrize("name", ["dragon", "bunny"])
+# dragon_dense: the same scene file with the frame-filling variant of the stand-in mesh (bench.py --scene dragon_dense).
+@pytest.mark.parametrize("name", ["dragon", "bunny", "dragon_dense"])
 def test_benchmark_scene_files_match_oracle(pkg, ctx, name):
     W, H, spp = 96, 54, 8
     scene = pkg.HostScene(S.scene_file(pkg, name), W, H)
-    assert scene.desc.num_tris == {"dragon": 868352, "bunny": 28576}[name]
+    assert scene.desc.num_tris == {"dragon": 868352, "bunny": 28576, "dragon_dense": 868352}[name]
     ctx.upload(scene)
     assert ctx.env_is_packed
     # (a) closest hits on primary + bounced + axis-parallel rays: bit-equal
@@ -245,6 +246,55 @@ def test_benchmark_scene_files_match_oracle(pkg, ctx, name):
     assert st.rays == ost.rays
     assert np.isfinite(ofilm).all() and np.isfinite(film).all() and (film >= 0).all()
     assert_same_film(film, ofilm, name)
+    if name == "dragon_dense":
+        # what makes it the traversal-bound workload: the mesh fills the frame and a ray visits many nodes
+        po, pd = O.primary_rays(S.as_oracle_desc(scene), W, H, sample=0, seed=1)
+        _, pprim, _, _ = O.intersect(S.as_oracle_desc(scene), po, pd)
+        assert (pprim < O.PRIM_SPHERE).mean() >= 0.8
+        assert ost.nodes / ost.rays >= 40
+
+
+def test_readme_configuration_matches_oracle(pkg, ctx):
+    """The configuration the reference's README times (README.md:76): scene/balls.scene as written (one plane, four spheres,
+    all four materials, thin lens, the 2048x1024 studio map stand-in) at 960x540 with 32 samples per pixel, loaded from the
+    scene file as the command line loads it.  Film and ray count bit-equal to the oracle's."""
+    W, H, spp = 960, 540, 32
+    scene = pkg.HostScene(S.scene_file(pkg, "balls"), W, H)
+    assert scene.desc.num_planes == 1 and scene.desc.num_spheres == 4 and scene.desc.num_nodes == 0
+    assert (scene.desc.env_width, scene.desc.env_height) == (2048, 1024)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(0, spp, spp, seed=0)
+    film = ctx.film_download()
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=0, nthreads=16)
+    assert st.paths == W * H * spp == ost.paths == 16588800
+    assert st.rays == ost.rays
+    assert np.isfinite(film).all()
+    assert_same_film(film, ofilm, "balls.scene 960x540x32")
+
+
+def test_4k_frame_in_three_slabs(pkg, ctx):
+    """A 3840x2160 frame of the dragon scene (the resolution of the largest benchmark configuration) with a sample slab that
+    holds two of its six samples per pixel: the call runs three slabs, starts every path once, traces the same rays and
+    gives the one-slab film up to the order in which a pixel's samples are added."""
+    W, H, spp = 3840, 2160, 6
+    scene = pkg.HostScene(S.scene_file(pkg, "dragon"), W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    try:
+        one = ctx.render(0, spp, spp, seed=2)
+        film_one = ctx.film_download()
+        ctx.film_clear()
+        ctx.set_option(pkg.OPT_SLAB_BYTES, 2 * W * H * 16)
+        three = ctx.render(0, spp, spp, seed=2)
+        film_three = ctx.film_download()
+    finally:
+        ctx.set_option(pkg.OPT_SLAB_BYTES, 32 << 30)
+    assert one.paths == three.paths == W * H * spp
+    assert one.rays == three.rays
+    assert np.isfinite(film_three).all() and (film_three >= 0).all()
+    assert np.allclose(film_three, film_one, rtol=1e-5, atol=1e-6)
+    print("4K x %d spp: one slab %.1f ms, three slabs %.1f ms" % (spp, one.ms_total, three.ms_total))
 
 
 @pytest.mark.parametrize("name", ["dragon", "bunny"])
@@ -508,6 +558,32 @@ def test_command_line_matches_library(pkg, ctx, tmp_path):
     assert r.returncode == 0, r.stderr
     assert '"gpus": 2' in r.stdout
     assert np.allclose(read_pfm(out2 + ".pfm"), cli, rtol=1e-5, atol=1e-7)
+
+
+def test_bench_starts_its_own_ranks(pkg):
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself and relays rank 0's line.  Rehearsal
+    form (PT_BENCH_REHEARSAL=1): both ranks on this one GPU, gloo for the reduce; the two ranks' shares of the samples sum
+    to the rays of a one-rank run of the same frame."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    args = ["--scene", "bunny", "--width", "256", "--height", "144", "--spp", "8", "--steps", "1", "--warmup", "0",
+            "--no-cpu-baseline"]
+    lines = []
+    for gpus in (2, 1):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus)] + args,
+                           env=dict(env, PT_BENCH_REHEARSAL="1"), cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(out) == 1
+        lines.append(json.loads(out[0]))
+    two, one = lines
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["rays_per_frame"] == one["config"]["rays_per_frame"]
+    assert abs(two["film_check"]["mean"] - one["film_check"]["mean"]) <= 1e-5 * one["film_check"]["mean"]
 
 
 def test_render_is_partition_invariant(pkg, ctx):

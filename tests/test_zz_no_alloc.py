@@ -71,3 +71,77 @@ def test_no_alloc_entry_point_rejects_what_its_scratch_cannot_hold(pkg, ctx):
         ctx.intersect_device_noalloc(n, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), t.data_ptr())
     st = ctx.intersect_device_noalloc(n - 1, buf.data_ptr(), buf.data_ptr(), buf.data_ptr(), t.data_ptr())
     assert st.rays == n - 1
+
+
+def test_no_alloc_entry_point_allocates_no_device_memory(pkg):
+    """The property the entry point exists for, on a fresh context whose first closest-hit call it is: the device's free
+    memory is the same before and after (hipMemGetInfo); the allocating entry point, called next with the same rays, does
+    take memory (its hit-id buffer), which shows that the measurement would see an allocation."""
+    import torch
+
+    c = pkg.Context(0)
+    try:
+        c.upload(S.parity_cases(pkg)["knot"])
+        g = np.load(os.path.join(S.GOLDEN, "rays_knot.npz"))
+        reps = (1 << 22) // g["org"].shape[0]                    # close to the 4 Mi rays the scratch holds: 16 MiB of hit ids
+        o4, d4 = _device_rays(np.tile(g["org"], (reps, 1)), np.tile(g["dir"], (reps, 1)))
+        n = o4.shape[0]
+        hit = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        t = torch.empty((n,), dtype=torch.float32, device="cuda")
+        # 64 rays first: whatever the HIP runtime itself sets up at a kernel's first launch is not this call's doing (a
+        # buffer of the library's own would grow with the ray count and show in the 4 Mi-ray calls below)
+        c.intersect_device_noalloc(64, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr())
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        c.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr())
+        c.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr(), want_stats=False)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert free1 == free0, "pt_intersect_device_noalloc changed the device's free memory by %d bytes" % (free0 - free1)
+        c.intersect_device(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr())
+        assert torch.cuda.mem_get_info()[0] < free0
+    finally:
+        c.close()
+
+
+def test_no_alloc_entry_point_queued_form(pkg, ctx):
+    """stats == NULL: the call only queues its two kernels on the context's stream (no memset, event, copy or wait); after
+    the stream has been waited for, the results are those of the synchronous form."""
+    import torch
+
+    g = np.load(os.path.join(S.GOLDEN, "rays_knot.npz"))
+    ctx.upload(S.parity_cases(pkg)["knot"])
+    o4, d4 = _device_rays(np.tile(g["org"], (20, 1)), np.tile(g["dir"], (20, 1)))
+    n = o4.shape[0]
+    hit = torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda")
+    t = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    assert ctx.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr(), want_stats=False) is None
+    torch.cuda.synchronize()                                      # device-wide: includes the context's own stream
+    assert np.array_equal(t.cpu().numpy(), np.tile(g["t"], 20))
+    assert np.array_equal(hit.cpu().numpy()[:, 3].view(np.uint32), np.tile(g["prim"], 20))
+
+
+def test_no_alloc_entry_point_on_deep_trees(pkg, ctx):
+    """A chain-shaped BVH 40 levels deep: deeper than the 26 stack slots the allocating entry point keeps in LDS (it sends the
+    rest through its global overflow array), while the variant, which has no such array, holds all 41 slots in LDS.  Rays
+    along the chain fill the stack to the bottom.  Both equal the oracle.  A tree of 50 levels needs 51 slots, more than
+    the 48 the variant's LDS-only stack may take: refused with PT_ERR_ARG, and still traced by the allocating entry point."""
+    import oracle_lib as O
+
+    for levels, fits in ((40, True), (50, False)):
+        scene = S.chain_scene(pkg, levels)
+        org, dir_ = S.chain_rays(levels, n=8192, seed=levels)
+        ot, oprim, _, _ = O.intersect(S.as_oracle_desc(scene), org, dir_)
+        assert (oprim == levels).mean() > 0.5                    # the rays that walk the whole chain hit its last triangle
+        ctx.upload(scene)
+        o4, d4 = _device_rays(org, dir_)
+        hit_a, t_a, _ = _run(ctx.intersect_device, o4, d4)
+        assert np.array_equal(t_a, ot) and np.array_equal(hit_a[:, 3].view(np.uint32), oprim)
+        if fits:
+            hit_b, t_b, _ = _run(ctx.intersect_device_noalloc, o4, d4)
+            assert np.array_equal(t_b, ot)
+            assert np.array_equal(hit_a.view(np.uint32), hit_b.view(np.uint32))
+        else:
+            with pytest.raises(pkg.PtError, match="stack slots"):
+                _run(ctx.intersect_device_noalloc, o4, d4)
