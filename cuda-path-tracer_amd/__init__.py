@@ -22,7 +22,6 @@ OPT_TUNE_EXTEND_BLOCKS = 10
 OPT_NODE_LAYOUT = 11
 OPT_TUNE_XCD_GROUP = 12
 OPT_RENDER_MODE, OPT_TUNE_PATH_WAVES, OPT_TUNE_PATH_REFILL, OPT_TUNE_PATH_LDS_SLOTS = 13, 14, 15, 16
-OPT_NORMAL_TABLE = 17
 
 
 class Plane(C.Structure):

@@ -79,9 +79,6 @@ struct DScene {
     // index of the triangle's mesh, 0).
     // A ref is a record index; refs >= first_tri are leaves.
     const float4 *recs;
-    // Per triangle record (index - first_tri): the unit normal the shading step needs (reference src/bvh.cuh:114,
-    // src/render.cu:41) and the reported primitive id, 16 B instead of a gather into the 64 B records; or NULL.
-    const float4 *tri_nrm;
     uint32_t first_tri;
     uint32_t stack_slots;    // traversal stack slots a ray can need: tree depth + 1
     const DPlane *planes;

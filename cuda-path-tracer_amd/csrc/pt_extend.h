@@ -175,12 +175,6 @@ __device__ __forceinline__ f3 hit_normal(const DScene &sc, uint32_t hid, f3 o, f
         const f3 p = {__fmaf_rn(d.x, t, o.x), __fmaf_rn(d.y, t, o.y), __fmaf_rn(d.z, t, o.z)};
         n = (p - xyz(pr)) / pr.w;
     } else {
-        if (sc.tri_nrm) {
-            // the same cross product and normalisation, evaluated once at upload with the same operation sequence
-            const float4 nv = sc.tri_nrm[hid - sc.first_tri];
-            prim = __float_as_uint(nv.w);
-            return xyz(nv);
-        }
         const float4 *rec = sc.recs + (size_t)hid * 4;
         n = cross3(xyz(rec[1]), xyz(rec[2]));
         prim = __float_as_uint(rec[3].x);

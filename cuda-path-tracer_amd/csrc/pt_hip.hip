@@ -120,7 +120,6 @@ struct pt_ctx {
     bool env_pack = true;      // use the packed environment texels when they are exact
     int xcd_group = 0;         // extend: each XCD's blocks work on one contiguous eighth of the ray buffer
     int node_layout = 1;       // 0: inner nodes in the order given, 1: parent + favoured child share a 128 B line
-    int normal_table = 1;      // 1: shading reads a triangle's unit normal from a 16 B table made at upload
     int render_mode = 1;       // 1: wavefront iterations over path buffers, 2: whole paths in one persistent kernel
     int path_waves = 0;        // k_path_stream: cap on resident waves per CU (0: as many as fit)
     int path_refill = 44;      // k_path_stream: service once this many lanes wait for it
@@ -847,7 +846,6 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         if (value > 1) return fail(ctx, PT_ERR_ARG, "node layout %llu unknown", (unsigned long long)value);
         ctx->node_layout = (int)value;
         return PT_OK;
-    case PT_OPT_NORMAL_TABLE: ctx->normal_table = value != 0; return PT_OK;
     case PT_OPT_RENDER_MODE:
         if (value != 1 && value != 2) return fail(ctx, PT_ERR_ARG, "render mode %llu unknown", (unsigned long long)value);
         ctx->render_mode = (int)value;
@@ -1042,26 +1040,6 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
         }
         int rc;
         if ((rc = upload_raw(ctx, recs.p, total_recs * 4, &sc.recs)) != PT_OK) return rc;
-        if (ctx->normal_table) {
-            // Unit normal + reported id of every triangle record: what the shading step needs of a hit triangle.  The
-            // device would form it as normalize3(cross3(row x, row y)) (pt_device.h); the same operations in the same
-            // order here (this file is compiled without contraction; fmaf, sqrtf and the division round correctly on
-            // both sides), so the table holds the very bits the kernels would compute.
-            const uint64_t T = total_recs - N;
-            HostArray<float4> nrm(T);
-            if (!nrm.p) return fail(ctx, PT_ERR_NOMEM, "pt_scene_upload: out of host memory");
-            parallel_chunks(T, host_threads(T), [&](size_t, uint64_t lo, uint64_t hi) {
-                for (uint64_t k = lo; k < hi; k++) {
-                    const float4 *r = recs.p + (N + k) * 4;
-                    const float4 a = r[1], b = r[2];
-                    const float cx = std::fmaf(a.y, b.z, -(a.z * b.y)), cy = std::fmaf(a.z, b.x, -(a.x * b.z)),
-                                cz = std::fmaf(a.x, b.y, -(a.y * b.x));
-                    const float s = 1.0f / std::sqrt(std::fmaf(cz, cz, std::fmaf(cy, cy, cx * cx)));
-                    nrm[k] = make_float4(cx * s, cy * s, cz * s, r[3].x);
-                }
-            });
-            if ((rc = upload_raw(ctx, nrm.p, T, &sc.tri_nrm)) != PT_OK) return rc;
-        }
         sc.first_tri = (uint32_t)N;
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;

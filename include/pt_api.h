@@ -157,9 +157,6 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 44) */
 #define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS; deeper entries go to a
                                        global array */
-#define PT_OPT_NORMAL_TABLE     17  /* 1 (default): pt_scene_upload also makes a 16 B per triangle table of unit normal + reported
-                                       id, which shading and the closest-hit entry points read instead of gathering the hit
-                                       triangle's 64 B record; 0: no table.  Same bits either way.  Read by pt_scene_upload. */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 

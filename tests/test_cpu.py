@@ -128,6 +128,23 @@ def test_host_bvh_equals_oracle(pkg, name, threads):
     assert a["max_depth"] == b["max_depth"] and a["num_leaves"] == b["num_leaves"]
 
 
+def test_bvh_builders_reproduce_the_handworked_tree(pkg):
+    """tests/golden/bvh_handworked.npz holds the node and triangle buffers of a six-triangle mesh worked out by hand from the
+    reference's text (bucket choice incl. a tie, std::partition's element order, ordering of two-triangle leaves, right-first
+    flatten, ~index leaf references, terminators, the zero pad, Woop rows; derivation in tools/make_golden_bvh_handworked.py,
+    which calls no builder).  The product's builder, with one thread and with four, and the oracle's reproduce it byte for
+    byte."""
+    g = np.load(os.path.join(S.GOLDEN, "bvh_handworked.npz"))
+    for what, b in (("oracle", O.bvh_build(g["verts"])), ("host, 1 thread", pkg.bvh_build(g["verts"], threads=1)),
+                    ("host, 4 threads", pkg.bvh_build(g["verts"], threads=4))):
+        assert b["nodes"].shape == (3, 16) and b["num_tri_float4"] == 23, what
+        assert b["nodes"].tobytes() == g["nodes"].tobytes(), what
+        assert b["tris"][:23].tobytes() == g["tris"].tobytes(), what
+        assert not b["tris"][23:].any(), what                       # the two float4 the leaf loop may read past the end
+        assert np.array_equal(b["prim_ids"][g["prim_index"]], g["prim_id"]), what
+        assert (b["num_tris"], b["num_leaves"]) == (6, 4), what
+
+
 def test_host_bvh_parallel_build_equals_serial(pkg):
     """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
     bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""
