@@ -182,6 +182,7 @@ def main():
     torch.cuda.synchronize()
 
     acc = {"rays": 0, "rays_escaped": 0, "ms_extend": 0.0, "ms_extend_busy": 0.0, "launches": 0, "ms_render": 0.0}
+    modes = set()
 
     def render_fn(begin, count, total, seed):
         st = ctx.render(begin, count, total, seed)
@@ -191,6 +192,7 @@ def main():
         acc["ms_extend_busy"] += st.ms_extend_busy
         acc["launches"] += st.extend_launches
         acc["ms_render"] += st.ms_total
+        modes.add(ctx.render_mode_used)
         return st
 
     def step(i):
@@ -206,6 +208,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     acc = {k: 0 for k in acc}
+    modes.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -254,6 +257,9 @@ def main():
                 "triangles": int(scene.desc.num_tris),
                 "rays_per_frame": int(total_rays / max(1, args.steps)),
                 "parallelism": "spp-partition x%d + film reduce" % world,
+                # 1: wavefront loop (bounce / generate / extend kernels over path buffers), 2: whole paths in one persistent
+                # kernel; chosen by the library from the scene unless --tune 13= forces one
+                "render_mode": sorted(modes)[0] if len(modes) == 1 else sorted(modes),
                 "scene_build_s": round(t_scene, 2),
             },
         }
@@ -328,6 +334,8 @@ def main():
                         pfile, str(cand.get("kernel_source_hash"))[:12], G.kernel_source_hash()[:12])
                 elif args.tune or args.pool or args.extend_mode != 2:
                     prof_why = "%s was taken with the default options" % pfile
+                elif cand.get("render_mode", 1) not in modes:
+                    prof_why = "%s was taken in render mode %r" % (pfile, cand.get("render_mode", 1))
                 else:
                     prof = cand
                     prof["file"] = pfile
@@ -335,8 +343,11 @@ def main():
             # b_ray is the mean over ALL rays.  Rays that were settled where they were created (one root visit in the
             # oracle's count) never reach an extend launch, so their bytes are taken out of what the launches are credited with.
             has_tree = int(scene.desc.num_nodes) > 0
-            ext_bytes = b_ray * acc["rays"] - acc["rays_escaped"] * (B_STATE + (64.0 if has_tree else 0.0))
-            ext_rays = acc["rays"] - acc["rays_escaped"]
+            whole_paths = modes == {2}          # the one kernel then handles every ray, the settled ones included
+            kernel = "k_path_stream" if whole_paths else "k_extend_stream"
+            settled_out = 0.0 if whole_paths else acc["rays_escaped"]
+            ext_bytes = b_ray * acc["rays"] - settled_out * (B_STATE + (64.0 if has_tree else 0.0))
+            ext_rays = acc["rays"] - settled_out
             launches = acc["launches"]
             avg_ms = acc["ms_extend"] / launches
             alg_launch = ext_bytes / (acc["ms_extend"] * 1e-3) / 1e9
@@ -351,7 +362,7 @@ def main():
                 # serialised, both from the committed profile of this command on these kernel sources.  Cannot exceed 1.
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_extend_stream",
+                "kernel": kernel,
                 "what_binds": "the rate at which a CU turns around per-lane 64 B record fetches that miss L1 (see record_rate); "
                               "HBM itself binds only where the tree does not fit the 256 MB Infinity Cache (--scene synth)",
                 "counters_source": prof["file"] if counters else None,
@@ -371,7 +382,7 @@ def main():
                     "over_frame": round(alg_frame / HBM_PEAK_GBS, 4),
                     "traffic_over_algorithmic": None if not traffic else round(traffic * launches / ext_bytes, 4),
                 },
-                "concurrent_streams": streams,
+                "concurrent_streams": 1 if whole_paths else streams,
                 "extend_busy_share_of_frame": round(acc["ms_extend_busy"] / max(1e-9, acc["ms_render"]), 3),
                 # rays that enter an extend launch (the ones a tree is traversed for) per second of frame time
                 "traversed_mrays_per_s": round(ext_rays / elapsed / 1e6, 1),
@@ -380,7 +391,7 @@ def main():
                 # 64 B records the launches fetch (every node visit and triangle test of the rays they trace) per second of
                 # the time at least one extend launch runs, against a bare dependent-gather loop at extend's own cache-hit
                 # mix and lane occupancy (tools/gather_probe2, figure from the committed profile)
-                recs = (trav[0] + trav[1]) * acc["rays"] - acc["rays_escaped"] * (1.0 if has_tree else 0.0)
+                recs = (trav[0] + trav[1]) * acc["rays"] - settled_out * (1.0 if has_tree else 0.0)
                 rate = recs / (acc["ms_extend_busy"] * 1e-3)
                 ceiling = None if not (counters and prof.get("probe_mixed_g_records_per_s")) else prof["probe_mixed_g_records_per_s"] * 1e9
                 roof["record_rate"] = {

@@ -152,6 +152,7 @@ def hip_lib():
         L.pt_film_reduce.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
         L.pt_render.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
         L.pt_env_is_packed.argtypes = [C.c_void_p]
+        L.pt_render_mode_used.argtypes = [C.c_void_p]
         L.pt_stream.restype = C.c_void_p
         L.pt_stream.argtypes = [C.c_void_p]
         _hip = L
@@ -406,6 +407,11 @@ class Context:
         st = Stats()
         self._check(self._L.pt_render(self._h, spp_begin, spp_count, spp_total, seed, C.byref(st)))
         return st
+
+    @property
+    def render_mode_used(self):
+        """1 wavefront loop, 2 whole-path kernel: what the last render ran in (0 before the first)."""
+        return self._L.pt_render_mode_used(self._h)
 
     @property
     def stream(self):

@@ -66,14 +66,14 @@ static hipError_t scratch_on_device(int device, unsigned char **out)
 // generate by streaming state through HBM, so one lane's extend runs beside another lane's bounce.  Measured on the
 // headline frame, 1 / 2 / 3 / 4 lanes: 324 / 280 / 269 / 288 ms.
 // blocks per CU the grids of bounce and generate are capped at (their blocks loop over the rays)
-#ifndef PT_BOUNCE_PER_CU
-#define PT_BOUNCE_PER_CU 8
-#endif
-#ifndef PT_GEN_PER_CU
-#define PT_GEN_PER_CU 8
-#endif
-constexpr int kBouncePerCu = PT_BOUNCE_PER_CU, kGenPerCu = PT_GEN_PER_CU;
+constexpr int kBouncePerCu = 8, kGenPerCu = 8;
 constexpr int kMaxLanes = 4;
+// Render mode chosen per scene (PT_OPT_RENDER_MODE 0): whole paths in one kernel when less than this share of the rays is
+// settled where they are made, else the wavefront loop.  The wavefront loop keeps settled rays out of the traversal kernel
+// and handles them in full waves; the whole-path kernel saves every ray's trip through the path buffers.  Measured on
+// MI355X, ms per 1920x1080 frame, wavefront / whole paths, with the settled share: spheres only (100 %) 50.9 / 60.7; bunny
+// (65 %) 139.5 / 156.3; dragon stand-in (53 %) 230 / 237; city (31 %) 100.9 / 97.6; frame-filling stand-in (4 %) 791 / 723.
+constexpr double kAutoSettledShare = 0.42;
 struct Lane {
     hipStream_t stream = nullptr;
     uint32_t pool_alloc = 0;
@@ -120,7 +120,11 @@ struct pt_ctx {
     bool env_pack = true;      // use the packed environment texels when they are exact
     int xcd_group = 0;         // extend: each XCD's blocks work on one contiguous eighth of the ray buffer
     int node_layout = 1;       // 0: inner nodes in the order given, 1: parent + favoured child share a 128 B line
-    int render_mode = 1;       // 1: wavefront iterations over path buffers, 2: whole paths in one persistent kernel
+    int render_mode = 0;       // 1: wavefront iterations over path buffers, 2: whole paths in one persistent kernel,
+                               // 0: chosen per scene from the first sample rendered (see kAutoSettledShare)
+    int auto_mode = 0;         // the choice made for the scene and film in place (0: not made yet)
+    double auto_settled = 0;   // the share of settled rays it was made on
+    int last_mode = 0;         // mode the last pt_render call ran in
     int path_waves = 0;        // k_path_stream: cap on resident waves per CU (0: as many as fit)
     int path_refill = 44;      // k_path_stream: service once this many lanes wait for it
     int path_lds_slots = 32;   // k_path_stream: traversal stack slots per lane kept in LDS
@@ -151,6 +155,7 @@ struct pt_ctx {
     Counters *cnt = nullptr;       // counters of the closest-hit entry points
     Counters *h_cnt = nullptr;     // pinned
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_slab_free = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;     // around a k_path_stream launch
 };
 
 static thread_local std::string g_create_err;
@@ -602,16 +607,23 @@ static bool node_layout_pairs(const float *nodes, uint64_t N, std::vector<uint32
     return pos == N && newid[0] == 0;
 }
 
-// pt_render with whole paths in one persistent kernel: per slab ONE k_path_stream launch over all its camera paths, then
-// the slab is folded into the film.  Everything is queued on the context's stream; the host waits once per slab for the
-// counters.
-static int render_paths(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint32_t s0, uint32_t s1,
-                        uint64_t slab_samples, pt_stats *stats)
+// What a pt_render call adds up over its slabs and kernels.
+struct RenderAcc {
+    pt_stats st{};
+    double ext_ms = 0;                                     // summed durations of the traversal launches
+    std::vector<std::pair<double, double>> ext_spans;     // begin, end of every traversal launch, ms after ev_begin
+};
+
+// Render mode 2 for the samples [first, first + count_s) of a slab whose entries for them start at `rows`: ONE k_path_stream
+// launch over all their camera paths on the context's stream, waited for; its counters are added to acc.
+// settled_share (may be NULL) receives the share of the launch's rays that were settled where they were made.
+static int paths_run(pt_ctx *ctx, uint64_t first, uint64_t count_s, float4 *rows, uint32_t s0, uint32_t s1, RenderAcc &acc,
+                     double *settled_share)
 {
     const uint32_t W = ctx->W, H = ctx->H, npix = W * H;
     hipStream_t st = ctx->stream;
-    // traversal stack: tree depth + 1 slots per lane, 256 B of LDS per slot and wave; beyond 40 slots (160 KB / 16 waves)
-    // the rest goes to a global array
+    // traversal stack: tree depth + 1 slots per lane, 256 B of LDS per slot and wave; beyond path_lds_slots the rest goes
+    // to a global array
     const uint32_t need = ctx->sc.has_bvh ? std::max<uint32_t>(1, ctx->sc.stack_slots) : 1;
     const int lds_slots = (int)std::min<uint32_t>(need, (uint32_t)ctx->path_lds_slots);
     const bool overflow = need > (uint32_t)lds_slots;
@@ -623,79 +635,117 @@ static int render_paths(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uin
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kPathBlock, shmem));
     if (per_cu < 1) return fail(ctx, PT_ERR_HIP, "pt_render: the path kernel does not fit a CU (%zu B of LDS)", shmem);
     if (ctx->path_waves > 0) per_cu = std::min(per_cu, ctx->path_waves);
-    if (std::getenv("PT_DEBUG"))
-        std::fprintf(stderr, "[pt] k_path_stream: %d waves per CU, %d stack slots in LDS%s, tree needs %u\n", per_cu, lds_slots,
-                     overflow ? ", overflow to global" : "", need);
     const uint32_t cps = (npix + kPathChunk - 1) / kPathChunk;
-    if ((uint64_t)cps * slab_samples >= 0xFFFF0000ull) return fail(ctx, PT_ERR_ARG, "pt_render: sample slab too large");
-    pt_stats acc{};
-    double kernel_ms = 0;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
-    for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
-        const uint64_t first = spp_begin + done_samples;
-        const uint64_t count_s = std::min<uint64_t>(slab_samples, spp_count - done_samples);
-        const uint32_t total_chunks = (uint32_t)(cps * count_s);
-        const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu,
-                                                                       ((uint64_t)npix * count_s + kPathBlock - 1) / kPathBlock));
-        if (overflow) {
-            const size_t threads = (size_t)grid * kPathBlock;
-            if (!ctx->gstk || ctx->gstk_threads < threads) {
-                if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; ctx->gstk_threads = 0; }
-                const size_t want = std::max(threads, (size_t)ctx->num_cus * 8 * kBlock);
-                HIPCHK(ctx, hipMalloc(&ctx->gstk, want * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
-                ctx->gstk_threads = want;
-            }
+    if ((uint64_t)cps * count_s >= 0xFFFF0000ull) return fail(ctx, PT_ERR_ARG, "pt_render: sample slab too large");
+    const uint32_t total_chunks = (uint32_t)(cps * count_s);
+    const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus * per_cu,
+                                                                   ((uint64_t)npix * count_s + kPathBlock - 1) / kPathBlock));
+    if (overflow) {
+        const size_t threads = (size_t)grid * kPathBlock;
+        if (!ctx->gstk || ctx->gstk_threads < threads) {
+            if (ctx->gstk) { (void)hipFree(ctx->gstk); ctx->gstk = nullptr; ctx->gstk_threads = 0; }
+            const size_t want = std::max(threads, (size_t)ctx->num_cus * 8 * kBlock);
+            HIPCHK(ctx, hipMalloc(&ctx->gstk, want * (size_t)(kMaxTreeDepth + 1) * sizeof(int)));
+            ctx->gstk_threads = want;
         }
-        PathArgs a{};
-        a.slab = ctx->slab;
-        a.slab_first_sample = (uint32_t)first;
-        a.W = W; a.H = H; a.npix = npix;
-        a.row_div = make_fastdiv(pixel_divisor(W, H));
-        a.chunks_per_sample = cps;
-        a.cps_div = make_fastdiv(cps);
-        a.total_chunks = total_chunks;
-        a.seed0 = s0; a.seed1 = s1;
-        a.cnt = ctx->pcnt;
-        a.refill_idle = ctx->path_refill;
-        a.lds_slots = lds_slots;
-        a.gstk = ctx->gstk;
-        HIPCHK(ctx, hipMemsetAsync(ctx->pcnt, 0, sizeof(PathCounters), st));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));          // re-used as "kernel begins" (timing enabled below)
-        const dim3 g(grid), b(kPathBlock);
-        if (overflow) {
-            if (count) hipLaunchKernelGGL((k_path_stream<true, true>), g, b, shmem, st, ctx->sc, a);
-            else hipLaunchKernelGGL((k_path_stream<true, false>), g, b, shmem, st, ctx->sc, a);
-        } else {
-            if (count) hipLaunchKernelGGL((k_path_stream<false, true>), g, b, shmem, st, ctx->sc, a);
-            else hipLaunchKernelGGL((k_path_stream<false, false>), g, b, shmem, st, ctx->sc, a);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
-        hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count_s, npix,
-                           (float)spp_total, ctx->film);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pcnt, ctx->pcnt, sizeof(PathCounters), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        float ms = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_slab_free, ctx->ev_end));
-        kernel_ms += ms;
-        const PathCounters &c = *ctx->h_pcnt;
-        acc.rays += c.rays;
-        acc.paths += c.paths;
-        acc.rays_escaped += c.settled;
-        acc.iterations += 1;
-        acc.extend_launches += 1;
-        acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
+    PathArgs a{};
+    a.slab = rows;
+    a.slab_first_sample = (uint32_t)first;
+    a.W = W; a.H = H; a.npix = npix;
+    a.row_div = make_fastdiv(pixel_divisor(W, H));
+    a.chunks_per_sample = cps;
+    a.cps_div = make_fastdiv(cps);
+    a.total_chunks = total_chunks;
+    a.seed0 = s0; a.seed1 = s1;
+    a.cnt = ctx->pcnt;
+    a.refill_idle = ctx->path_refill;
+    a.lds_slots = lds_slots;
+    a.gstk = ctx->gstk;
+    HIPCHK(ctx, hipMemsetAsync(ctx->pcnt, 0, sizeof(PathCounters), st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_k0, st));
+    const dim3 g(grid), b(kPathBlock);
+    if (overflow) {
+        if (count) hipLaunchKernelGGL((k_path_stream<true, true>), g, b, shmem, st, ctx->sc, a);
+        else hipLaunchKernelGGL((k_path_stream<true, false>), g, b, shmem, st, ctx->sc, a);
+    } else {
+        if (count) hipLaunchKernelGGL((k_path_stream<false, true>), g, b, shmem, st, ctx->sc, a);
+        else hipLaunchKernelGGL((k_path_stream<false, false>), g, b, shmem, st, ctx->sc, a);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev_k1, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pcnt, ctx->pcnt, sizeof(PathCounters), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (stats) {
-        float ms = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
-        acc.ms_total = ms;
-        acc.ms_extend = kernel_ms;
-        acc.ms_extend_busy = kernel_ms;
-        *stats = acc;
+    float t0 = 0, ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&t0, ctx->ev_begin, ctx->ev_k0));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k0, ctx->ev_k1));
+    acc.ext_ms += ms;
+    acc.ext_spans.push_back({(double)t0, (double)t0 + ms});
+    const PathCounters &c = *ctx->h_pcnt;
+    acc.st.rays += c.rays;
+    acc.st.paths += c.paths;
+    acc.st.rays_escaped += c.settled;
+    acc.st.iterations += 1;
+    acc.st.extend_launches += (ctx->sc.has_bvh && c.rays > c.settled) ? 1 : 0;
+    acc.st.nodes += c.trav[0]; acc.st.tris += c.trav[1]; acc.st.leaves += c.trav[2];
+    if (settled_share) *settled_share = c.rays ? (double)c.settled / (double)c.rays : 1.0;
+    return PT_OK;
+}
+
+// Render mode 1 for the samples [first, first + count) of a slab whose entries for them start at `rows`: the samples are
+// split over the lanes, the lanes' iterations are queued round robin until every lane has run out of work, and the
+// context's stream is made to wait for them (on the device), so that what the caller queues there next -- the pass that
+// folds the slab into the film -- starts when the last lane ends.  Returns the number of lanes used; their counters are
+// on their way to pinned memory and are read by wavefront_collect once the caller has waited for the context's stream.
+static int wavefront_run(pt_ctx *ctx, uint64_t first, uint64_t count, float4 *rows, uint32_t s0, uint32_t s1, int *lanes_used)
+{
+    const uint32_t npix = ctx->W * ctx->H;
+    hipStream_t st = ctx->stream;
+    // Which lane renders a sample does not change its slab entry, so the film does not depend on the lane count.
+    const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
+    *lanes_used = nl;
+    for (int k = 0; k < nl; k++) {
+        const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
+        int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, rows + (size_t)b * npix, nl);
+        if (rc != PT_OK) return rc;
+    }
+    // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
+    for (int live = nl; live > 0;) {
+        for (int k = 0; k < nl; k++) {
+            Lane &ln = ctx->lanes[k];
+            if (ln.done) continue;
+            int rc = lane_iterate(ctx, ln, s0, s1);
+            if (rc != PT_OK) return rc;
+            if (ln.done) live--;
+        }
+    }
+    for (int k = 0; k < nl; k++) {
+        Lane &ln = ctx->lanes[k];
+        HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[0], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ln.stream));
+        HIPCHK(ctx, hipEventRecord(ln.ev_done, ln.stream));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ln.ev_done, 0));
+    }
+    return PT_OK;
+}
+
+static int wavefront_collect(pt_ctx *ctx, int nl, RenderAcc &acc)
+{
+    for (int k = 0; k < nl; k++) {
+        Lane &ln = ctx->lanes[k];
+        const Counters &c = ln.h_cnt[0];
+        acc.st.rays += c.rays_total;
+        acc.st.paths += c.paths_total;
+        acc.st.iterations += c.iter;
+        acc.st.extend_launches += c.extend_nonempty;
+        acc.st.rays_escaped += c.escaped_total;
+        acc.st.nodes += c.trav[0]; acc.st.tris += c.trav[1]; acc.st.leaves += c.trav[2];
+        for (size_t i = 0; i + 1 < ln.ev_used; i += 2) {
+            float b = 0, e = 0;
+            HIPCHK(ctx, hipEventElapsedTime(&b, ctx->ev_begin, ln.events[i]));
+            HIPCHK(ctx, hipEventElapsedTime(&e, ln.events[i], ln.events[i + 1]));
+            acc.ext_ms += e;
+            acc.ext_spans.push_back({(double)b, (double)b + e});
+        }
     }
     return PT_OK;
 }
@@ -744,6 +794,8 @@ int pt_ctx_create(int device, pt_ctx **out)
     CREATECHK(hipEventCreate(&ctx->ev_begin));
     CREATECHK(hipEventCreate(&ctx->ev_end));
     CREATECHK(hipEventCreate(&ctx->ev_slab_free));
+    CREATECHK(hipEventCreate(&ctx->ev_k0));
+    CREATECHK(hipEventCreate(&ctx->ev_k1));
 #undef CREATECHK
     {
         std::lock_guard<std::mutex> lock(g_rccl_mu);
@@ -790,6 +842,8 @@ void pt_ctx_destroy(pt_ctx *ctx)
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     if (ctx->ev_slab_free) (void)hipEventDestroy(ctx->ev_slab_free);
+    if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+    if (ctx->ev_k1) (void)hipEventDestroy(ctx->ev_k1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -847,7 +901,7 @@ int pt_set_option(pt_ctx *ctx, int option, uint64_t value)
         ctx->node_layout = (int)value;
         return PT_OK;
     case PT_OPT_RENDER_MODE:
-        if (value != 1 && value != 2) return fail(ctx, PT_ERR_ARG, "render mode %llu unknown", (unsigned long long)value);
+        if (value > 2) return fail(ctx, PT_ERR_ARG, "render mode %llu unknown", (unsigned long long)value);
         ctx->render_mode = (int)value;
         return PT_OK;
     case PT_OPT_TUNE_PATH_WAVES:
@@ -1128,6 +1182,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
     sc.cam = s->camera;
     ctx->sc = sc;
     ctx->have_scene = true;
+    ctx->auto_mode = 0;
     replace.complete = true;
     return PT_OK;
 }
@@ -1339,6 +1394,7 @@ int pt_film_bind(pt_ctx *ctx, uint32_t W, uint32_t H, void *device_film)
     ctx->film = nullptr;
     ctx->film_owned = false;
     ctx->W = W; ctx->H = H;
+    ctx->auto_mode = 0;
     if (device_film) {
         ctx->film = (float *)device_film;
     } else {
@@ -1474,77 +1530,55 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
         ctx->slab_bytes = slab_samples * per_sample;
     }
 
-    if (ctx->render_mode == 2) return render_paths(ctx, spp_begin, spp_count, spp_total, s0, s1, slab_samples, stats);
-
-    pt_stats acc{};
-    double ext_ms = 0;
-    std::vector<std::pair<double, double>> ext_spans;    // begin, end of every extend launch, ms after ev_begin
+    RenderAcc acc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_begin, st));
     HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));
 
     for (uint64_t done_samples = 0; done_samples < spp_count; done_samples += slab_samples) {
         const uint64_t first = spp_begin + done_samples;
         const uint64_t count = std::min<uint64_t>(slab_samples, spp_count - done_samples);
-
-        // The slab's samples are split over the lanes (see Lane).  Which lane renders a sample does not change its slab
-        // entry, so the film does not depend on the lane count.
-        const int nl = (int)std::min<uint64_t>((uint64_t)ctx->nlanes, count);
-        for (int k = 0; k < nl; k++) {
-            const uint64_t b = count * k / nl, e = count * (k + 1) / nl;
-            int rc = lane_begin(ctx, ctx->lanes[k], first + b, e - b, ctx->slab + (size_t)b * npix, nl);
+        uint64_t done_here = 0;
+        int mode = ctx->render_mode ? ctx->render_mode : ctx->auto_mode;
+        if (mode == 0) {
+            // Not decided yet for this scene and film: the slab's first sample is rendered by the whole-path kernel (work that
+            // has to be done anyway; its slab entries are the ones either mode writes), and the share of its rays that were
+            // settled where they were made decides the mode for everything after it.
+            double settled = 1.0;
+            int rc = paths_run(ctx, first, 1, ctx->slab, s0, s1, acc, &settled);
+            if (rc != PT_OK) return drain_lanes(ctx, rc);
+            ctx->auto_mode = settled < kAutoSettledShare ? 2 : 1;
+            ctx->auto_settled = settled;
+            mode = ctx->auto_mode;
+            done_here = 1;
+        }
+        int nl = 0;
+        if (done_here < count) {
+            float4 *rows = ctx->slab + (size_t)done_here * npix;
+            int rc = mode == 2 ? paths_run(ctx, first + done_here, count - done_here, rows, s0, s1, acc, nullptr)
+                               : wavefront_run(ctx, first + done_here, count - done_here, rows, s0, s1, &nl);
             if (rc != PT_OK) return drain_lanes(ctx, rc);
         }
-        // round robin: one iteration per live lane, so that the lanes' kernels are queued side by side
-        for (int live = nl; live > 0;) {
-            for (int k = 0; k < nl; k++) {
-                Lane &ln = ctx->lanes[k];
-                if (ln.done) continue;
-                int rc = lane_iterate(ctx, ln, s0, s1);
-                if (rc != PT_OK) return drain_lanes(ctx, rc);
-                if (ln.done) live--;
-            }
-        }
         // every path of this slab has ended and its entry holds what it contributes: fold the slab into the film
-        for (int k = 0; k < nl; k++) {
-            Lane &ln = ctx->lanes[k];
-            HIPCHK(ctx, hipMemcpyAsync(&ln.h_cnt[0], ln.cnt, sizeof(Counters), hipMemcpyDeviceToHost, ln.stream));
-            HIPCHK(ctx, hipEventRecord(ln.ev_done, ln.stream));
-            HIPCHK(ctx, hipStreamWaitEvent(st, ln.ev_done, 0));
-        }
         hipLaunchKernelGGL(k_film_reduce, dim3(stream_grid(ctx, npix)), dim3(kBlock), 0, st, ctx->slab, (uint32_t)count, npix,
                            (float)spp_total, ctx->film);
         HIPCHK(ctx, hipEventRecord(ctx->ev_slab_free, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         HIPCHK(ctx, hipGetLastError());
-        for (int k = 0; k < nl; k++) {
-            Lane &ln = ctx->lanes[k];
-            const Counters &c = ln.h_cnt[0];
-            acc.rays += c.rays_total;
-            acc.paths += c.paths_total;
-            acc.iterations += c.iter;
-            acc.extend_launches += c.extend_nonempty;
-            acc.rays_escaped += c.escaped_total;
-            acc.nodes += c.trav[0]; acc.tris += c.trav[1]; acc.leaves += c.trav[2];
-            for (size_t i = 0; i + 1 < ln.ev_used; i += 2) {
-                float b = 0, e = 0;
-                HIPCHK(ctx, hipEventElapsedTime(&b, ctx->ev_begin, ln.events[i]));
-                HIPCHK(ctx, hipEventElapsedTime(&e, ln.events[i], ln.events[i + 1]));
-                ext_ms += e;
-                ext_spans.push_back({(double)b, (double)b + e});
-            }
-        }
+        int rc = wavefront_collect(ctx, nl, acc);
+        if (rc != PT_OK) return rc;
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_end, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->last_mode = ctx->render_mode ? ctx->render_mode : ctx->auto_mode;
     if (stats) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
-        acc.ms_total = ms;
-        acc.ms_extend = ext_ms;
-        // length of the union of the extend launches' time spans
-        std::sort(ext_spans.begin(), ext_spans.end());
+        acc.st.ms_total = ms;
+        acc.st.ms_extend = acc.ext_ms;
+        // length of the union of the traversal launches' time spans
+        std::sort(acc.ext_spans.begin(), acc.ext_spans.end());
         double busy = 0, cur_b = 0, cur_e = -1;
-        for (const auto &sp : ext_spans) {
+        for (const auto &sp : acc.ext_spans) {
             if (sp.first > cur_e) {
                 if (cur_e > cur_b) busy += cur_e - cur_b;
                 cur_b = sp.first;
@@ -1554,10 +1588,12 @@ int pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_
             }
         }
         if (cur_e > cur_b) busy += cur_e - cur_b;
-        acc.ms_extend_busy = busy;
-        *stats = acc;
+        acc.st.ms_extend_busy = busy;
+        *stats = acc.st;
     }
     return PT_OK;
 }
+
+int pt_render_mode_used(const pt_ctx *ctx) { return ctx ? ctx->last_mode : PT_ERR_ARG; }
 
 }   // extern "C"

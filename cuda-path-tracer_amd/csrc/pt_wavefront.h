@@ -226,35 +226,12 @@ __device__ __forceinline__ int path_step(const DScene &sc, PathRay &R, uint32_t 
     return !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
 }
 
-// Steps a path for as long as the ray it continues with is settled where it is made (at most kPathTrips steps): such a
-// ray would otherwise be written to the path buffer with its hit (48 + 8 B), read back by the next bounce launch (56 B)
-// and shaded there.  `consumed` counts the settled rays that were shaded here instead (per lane; they take no slot but
-// are rays all the same).  The film does not depend on where a ray is shaded: random numbers are keyed on the path.
-#ifndef PT_PATH_TRIPS
-#define PT_PATH_TRIPS 1
-#endif
-constexpr int kPathTrips = PT_PATH_TRIPS;
-__device__ __forceinline__ int path_run(const DScene &sc, PathRay &R, uint32_t pixel, float4 *__restrict__ slab_entry,
-                                        uint32_t seed0, uint32_t seed1, uint32_t &consumed)
-{
-    int cls;
-    for (int trip = 0;; trip++) {
-        cls = path_step(sc, R, pixel, slab_entry, seed0, seed1);
-        if (cls != RAY_BACK || trip + 1 == kPathTrips) break;
-        consumed++;
-    }
-    return cls;
-}
-
 // threads per block = rays per output claim.  The threads of a block move in lock step (two barriers per batch), so a
 // smaller block lets more of the gathers of different batches overlap; a larger one needs fewer of the same-address
 // atomics, which all blocks of all kernels of a stream share.  Measured ms per frame (868 k-triangle stand-in / spheres
 // only) with generate at 512: bounce 64 -> 345 / 130, 128 -> 271 / 87, 256 -> 251 / 72.6, 512 -> 260 / 75.8,
 // 1024 -> 265 / 80; with bounce at 256, generate 256 -> 249 / 77.4.
-#ifndef PT_BOUNCEBLOCK
-#define PT_BOUNCEBLOCK 256
-#endif
-constexpr int kBounceBlock = PT_BOUNCEBLOCK;
+constexpr int kBounceBlock = 256;
 
 // slot of the i-th ray of a buffer whose front holds n_front rays and whose back holds the rest
 __device__ __forceinline__ uint32_t buffer_slot(uint32_t i, uint32_t n_front, uint32_t n_total, uint32_t P)
@@ -338,7 +315,7 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
 {
     __shared__ uint32_t s_wave[2][kBounceBlock / 64];
     __shared__ unsigned long long s_base[2];
-    uint32_t escaped = 0, consumed = 0;
+    uint32_t escaped = 0;
     const uint32_t n_front = cnt->n_in;
     const uint32_t n = n_front + cnt->n_back_in;
     const uint32_t stride = gridDim.x * kBounceBlock;
@@ -357,7 +334,7 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
         int cls = RAY_DROP;
         if (i < n) {
             const uint32_t sample = __float_as_uint(in.th.w) & 0x07FFFFFFu;
-            cls = path_run(sc, R, pixel, slab + (size_t)(sample - slab_first_sample) * npix + pixel, seed0, seed1, consumed);
+            cls = path_step(sc, R, pixel, slab + (size_t)(sample - slab_first_sample) * npix + pixel, seed0, seed1);
         }
         const uint32_t dst = block_append<kBounceBlock>(cls, cnt, P, s_wave, s_base, par, escaped);
         if (cls == RAY_FRONT || cls == RAY_BACK) {
@@ -370,7 +347,7 @@ __global__ __launch_bounds__(kBounceBlock) __attribute__((amdgpu_waves_per_eu(5,
             }
         }
     }
-    flush_escaped(cnt, escaped, consumed);
+    flush_escaped(cnt, escaped, 0u);
 }
 
 // --------------------------------------------------------------------------------------------------------------
@@ -394,10 +371,7 @@ __global__ void k_take(Counters *cnt, uint32_t P, uint32_t cap)
 // threads per block = paths per output claim.  512 while the kernel only made camera rays; since it also shades the camera
 // hits that are settled here (gathers, like bounce) 256: 234.6 ms against 238.8 (512), 243.7 (1024), 244.6 (128) on the
 // 868 k-triangle frame, 51.0 against 55.3 on the spheres-only frame.
-#ifndef PT_GENBLOCK
-#define PT_GENBLOCK 256
-#endif
-constexpr int kGenBlock = PT_GENBLOCK;
+constexpr int kGenBlock = 256;
 // waves_per_eu(6): 80 VGPRs (8 B of scratch per lane) instead of 98, a sixth wave per SIMD for the gathers of the camera
 // hits that are shaded here.  Measured with bounce at 5 / 6 and generate at 5 / 6 waves: 240.9 ms (5, 5), 238.5 (5, 6),
 // 243.1 (6, 5), 240.6 (6, 6), 249.3 (7, 7) on the 868 k-triangle frame.
@@ -445,8 +419,9 @@ __global__ __launch_bounds__(kGenBlock) __attribute__((amdgpu_waves_per_eu(6, 8)
             cls = !settled ? RAY_FRONT : (nhid == PT_PRIM_MISS ? RAY_ESCAPED : RAY_BACK);
             // A camera ray that is settled here is dealt with here, exactly as the bounce kernel would one iteration later.
             // One that leaves the scene: its path ends, path_step writes its slab entry.  One whose hit is a plane or sphere
-            // in front of the mesh: it is shaded now (and so is what follows, while that is settled too), so the path leaves
-            // this kernel with a later ray and the camera ray's trip through the path buffers is saved.
+            // in front of the mesh: it is shaded now, so the path leaves this kernel with its second ray and the camera ray's
+            // trip through the path buffers is saved.  (Going on in registers while the next ray is settled too was
+            // measured slower: the few lanes that go round hold their wave.)
             // A camera ray that needs the tree gets its slab entry from the bounce kernel (when it is shaded, or when the
             // tree reports a miss): waves whose pixels all show the mesh skip the environment lookup altogether.
             if (cls != RAY_FRONT) {
@@ -454,7 +429,7 @@ __global__ __launch_bounds__(kGenBlock) __attribute__((amdgpu_waves_per_eu(6, 8)
                 R.o = o; R.d = d; R.t = nt; R.hid = nhid; R.th = th;
                 const bool hit = cls == RAY_BACK;
                 consumed += hit ? 1u : 0u;
-                const int c = path_run(sc, R, pixel, slab + (size_t)s_local * npix + pixel, seed0, seed1, consumed);
+                const int c = path_step(sc, R, pixel, slab + (size_t)s_local * npix + pixel, seed0, seed1);
                 if (hit) {
                     cls = c;
                     o = R.o; d = R.d; th = R.th; nt = R.t; nhid = R.hid;

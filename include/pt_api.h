@@ -149,10 +149,13 @@ typedef struct pt_ctx pt_ctx;
 #define PT_OPT_NODE_LAYOUT      11  /* 1 (default): inner nodes are re-ordered at upload so that a node and the child a ray most
                                        likely visits next share a 128 B cache line; 0: the order given.  Hits do not depend on
                                        it.  Read by pt_scene_upload. */
-#define PT_OPT_RENDER_MODE      13  /* 1 (default): wavefront iterations over path buffers (bounce / generate / extend kernels on
+#define PT_OPT_RENDER_MODE      13  /* 1: wavefront iterations over path buffers (bounce / generate / extend kernels on
                                        PT_OPT_STREAMS streams); 2: every camera path is traced from first ray to end by one
                                        lane of a persistent kernel (traversal steps, logic and shading in the same wave; no
-                                       path buffers).  The film does not depend on it. */
+                                       path buffers); 0 (default): chosen for the scene and film in place by the first
+                                       pt_render call after pt_scene_upload / pt_film_bind, from its first sample: mode 2 when
+                                       fewer than 42 % of that sample's rays are settled where they are made (nothing below
+                                       the BVH root can stop them), else mode 1.  The film does not depend on the mode. */
 #define PT_OPT_TUNE_PATH_WAVES  14  /* render mode 2 tuning: cap on resident waves per CU (0 = as many as fit, default) */
 #define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 44) */
 #define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS; deeper entries go to a
@@ -241,6 +244,10 @@ int  pt_film_reduce(pt_ctx *const *ctxs, int n, int root);
  * sample per pixel rendered at a time (see PT_OPT_SLAB_BYTES). */
 int  pt_render(pt_ctx *ctx, uint64_t spp_begin, uint64_t spp_count, uint64_t spp_total, uint64_t seed,
                pt_stats *stats);
+
+/* Render mode (1 or 2, see PT_OPT_RENDER_MODE) the last pt_render call of the context ran in; 0 before the first.  No reference
+ * counterpart. */
+int  pt_render_mode_used(const pt_ctx *ctx);
 
 /* 1 when the uploaded scene keeps its environment texels in the packed form (see PT_OPT_ENV_PACK), 0 when not,
  * negative without a scene.  No reference counterpart. */

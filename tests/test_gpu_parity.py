@@ -111,6 +111,7 @@ def test_traversal_tuning_changes_no_answer(pkg, ctx):
         ctx.render(0, spp, spp, seed=21)
         return t, prim, ctx.film_download()
 
+    ctx.set_option(pkg.OPT_RENDER_MODE, 1)            # the options below tune the wavefront loop's traversal kernel
     _, _, film0 = answers()
     defaults = {pkg.OPT_TUNE_LDS_SLOTS: 26, pkg.OPT_TUNE_REFILL_IDLE: 44, pkg.OPT_TUNE_EXTEND_BLOCKS: 8,
                 pkg.OPT_TUNE_XCD_GROUP: 0, pkg.OPT_NODE_LAYOUT: 1}
@@ -128,6 +129,7 @@ def test_traversal_tuning_changes_no_answer(pkg, ctx):
     finally:
         for opt, value in defaults.items():
             ctx.set_option(opt, value)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
 
 
 def test_primary_rays_bit_exact(pkg, ctx):
@@ -611,14 +613,18 @@ def test_render_small_pool_many_iterations(pkg, ctx):
     scene = S.knot_scene(pkg, W, H)
     ctx.upload(scene)
     ctx.film_bind(W, H)
-    ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
-    ctx.render(0, spp, spp, seed=9)
-    big = ctx.film_download()
-    ctx.film_clear()
-    ctx.set_option(pkg.OPT_POOL_SIZE, 1024)
-    st = ctx.render(0, spp, spp, seed=9)
-    small = ctx.film_download()
-    ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
+    ctx.set_option(pkg.OPT_RENDER_MODE, 1)            # the pool belongs to the wavefront loop
+    try:
+        ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
+        ctx.render(0, spp, spp, seed=9)
+        big = ctx.film_download()
+        ctx.film_clear()
+        ctx.set_option(pkg.OPT_POOL_SIZE, 1024)
+        st = ctx.render(0, spp, spp, seed=9)
+        small = ctx.film_download()
+    finally:
+        ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
     assert st.iterations >= W * H * spp // 1024
     assert st.paths == W * H * spp
     assert np.array_equal(small, big), "the film depends on the pool size"
@@ -633,6 +639,7 @@ def test_render_film_size_that_does_not_tile(pkg, ctx):
     ctx.upload(scene)
     ctx.film_bind(W, H)
     films = []
+    ctx.set_option(pkg.OPT_RENDER_MODE, 1)
     try:
         for pool in (1 << 22, 1024, 4096 + 512):
             ctx.set_option(pkg.OPT_POOL_SIZE, pool)
@@ -642,6 +649,7 @@ def test_render_film_size_that_does_not_tile(pkg, ctx):
             films.append(ctx.film_download())
     finally:
         ctx.set_option(pkg.OPT_POOL_SIZE, 1 << 22)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
     assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=13)
     assert st.rays == ost.rays
@@ -737,6 +745,7 @@ def test_film_does_not_depend_on_the_stream_count(pkg, ctx):
     ctx.upload(scene)
     ctx.film_bind(W, H)
     films = []
+    ctx.set_option(pkg.OPT_RENDER_MODE, 1)
     try:
         for lanes in (1, 2, 3, 4):
             ctx.set_option(pkg.OPT_STREAMS, lanes)
@@ -746,6 +755,7 @@ def test_film_does_not_depend_on_the_stream_count(pkg, ctx):
             films.append(ctx.film_download())
     finally:
         ctx.set_option(pkg.OPT_STREAMS, 3)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
     for f in films[1:]:
         assert np.array_equal(f, films[0])
     with pytest.raises(pkg.PtError):
@@ -840,7 +850,9 @@ def test_whole_path_kernel_matches_oracle(pkg, ctx, name):
     ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=21)
     ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 1)
     try:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 1)
         wst = ctx.render(0, spp, spp, seed=21)
+        assert ctx.render_mode_used == 1
         assert_same_film(ctx.film_download(), ofilm, name + " wavefront")
         ctx.set_option(pkg.OPT_RENDER_MODE, 2)
         for refill, lds in ((44, 32), (1, 32), (64, 32), (44, 3)):
@@ -850,14 +862,58 @@ def test_whole_path_kernel_matches_oracle(pkg, ctx, name):
             st = ctx.render(0, spp, spp, seed=21)
             what = "%s threshold %d, %d LDS slots" % (name, refill, lds)
             assert_same_film(ctx.film_download(), ofilm, what)
+            assert ctx.render_mode_used == 2
             assert st.paths == W * H * spp and st.rays == ost.rays == wst.rays, what
             assert st.rays_escaped == wst.rays_escaped, what
             assert (st.nodes, st.tris, st.leaves) == (ost.nodes, ost.tris, ost.leaves) == (wst.nodes, wst.tris, wst.leaves), what
     finally:
-        ctx.set_option(pkg.OPT_RENDER_MODE, 1)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
         ctx.set_option(pkg.OPT_TUNE_PATH_REFILL, 44)
         ctx.set_option(pkg.OPT_TUNE_PATH_LDS_SLOTS, 32)
         ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 0)
+
+
+def test_render_mode_is_chosen_from_the_first_sample(pkg, ctx):
+    """PT_OPT_RENDER_MODE 0 (the default): the first render after an upload traces its first sample with the whole-path kernel
+    and picks the mode for the rest from the share of that sample's rays that were settled where they were made.  A mesh that
+    fills the frame gets mode 2, a scene of spheres mode 1; the film is the oracle's either way, counters included, also when
+    the call runs slab after slab (the pilot sample is part of the first slab) and on the calls after the choice was made."""
+    W, H, spp = 96, 64, 6
+    cases = {"city": (lambda: pkg.HostScene(S.scene_file(pkg, "city"), W, H), 2),
+             "balls": (lambda: S.spheres_scene(pkg, W, H), 1)}
+    for name, (make, want_mode) in cases.items():
+        scene = make()
+        ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=31)
+        ctx.upload(scene)                                    # forgets an earlier choice
+        ctx.film_bind(W, H)
+        ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 1)
+        try:
+            for call in range(2):                            # the first call chooses, the second finds the choice made
+                ctx.film_clear()
+                st = ctx.render(0, spp, spp, seed=31)
+                assert ctx.render_mode_used == want_mode, name
+                assert_same_film(ctx.film_download(), ofilm, "%s, call %d" % (name, call))
+                assert st.paths == W * H * spp and st.rays == ost.rays
+                assert (st.nodes, st.tris, st.leaves) == (ost.nodes, ost.tris, ost.leaves)
+            ctx.upload(scene)
+            ctx.set_option(pkg.OPT_SLAB_BYTES, 1 << 20)
+            ctx.film_bind(W * 4, H * 4)                      # 1.5 MB of slab per sample, 1 MiB allowed: a slab per sample
+            st = ctx.render(0, 3, 3, seed=31)
+            # (the camera depends on the film's aspect ratio only, so the same scene serves the larger film)
+            big, _ = O.render(S.as_oracle_desc(scene), W * 4, H * 4, 0, 3, 3, seed=31)
+            assert st.paths == W * H * 16 * 3
+            assert np.allclose(ctx.film_download(), big, rtol=1e-5, atol=1e-7)
+        finally:
+            ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 0)
+            ctx.set_option(pkg.OPT_SLAB_BYTES, 32 << 30)
+    # a single-sample call is the pilot alone
+    scene = S.spheres_scene(pkg, W, H)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    st = ctx.render(2, 1, 4, seed=3)
+    o, ost = O.render(S.as_oracle_desc(scene), W, H, 2, 1, 4, seed=3)
+    assert st.rays == ost.rays
+    assert_same_film(ctx.film_download(), o, "one sample")
 
 
 def test_whole_path_kernel_slabs_partition_and_odd_sizes(pkg, ctx):
@@ -884,7 +940,7 @@ def test_whole_path_kernel_slabs_partition_and_odd_sizes(pkg, ctx):
         ctx.render(3, spp - 3, spp, seed=5)
         assert np.allclose(ctx.film_download(), ofilm, rtol=1e-5, atol=1e-7)
     finally:
-        ctx.set_option(pkg.OPT_RENDER_MODE, 1)
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
         ctx.set_option(pkg.OPT_SLAB_BYTES, 32 << 30)
 
 
