@@ -74,12 +74,11 @@ struct DSphere { float4 pos_r; float4 mat; uint32_t type; uint32_t pad[3]; };   
 struct DMesh { float4 mat; uint32_t type; uint32_t pad[3]; };                             // 32 B
 
 struct DScene {
-    // 64 B records.  [0, first_tri): inner nodes = left xy box, right xy box, both z ranges, (left ref, right ref, 0, 0);
-    // [first_tri, ...): triangles = Woop rows z, x, y and (prim id, flags: 1 = last of its leaf, 2 = null record,
-    // index of the triangle's mesh, 0).
-    // A ref is a record index; refs >= first_tri are leaves.
+    // 64 B records, record 0 the root.  Inner node = left xy box, right xy box, both z ranges, (left ref, right ref, 0, 0);
+    // triangle = Woop rows z, x, y and (prim id, flags: 1 = last of its leaf, 2 = null record, index of the triangle's
+    // mesh, 0).  A ref is a record index (30 bits); refs to leaves have the sign bit set.  Which record sits where is
+    // decided at upload (see pt_scene_upload).
     const float4 *recs;
-    uint32_t first_tri;
     uint32_t stack_slots;    // traversal stack slots a ray can need: tree depth + 1
     const DPlane *planes;
     const DSphere *spheres;

@@ -1,10 +1,10 @@
 // extend: closest hit of every ray of a buffer (reference src/render.cu:11-44, src/bvh.cuh:130-189).
 //
-// The BVH is one array of 64 B records: inner nodes first (two child boxes + two child references), triangle records
-// after them (three Woop rows + id/flags).  A child reference is the index of a record; references >= first_tri are
-// leaves (runs of triangle records ended by a "last" flag).  Every traversal step, inner node or triangle, therefore is
-// "fetch 64 B at recs + 64 * ref, then compute", and a lane's traversal stack is a column of an LDS array whose bottom
-// slot holds the sentinel that ends the traversal.
+// The BVH is one array of 64 B records: inner nodes (two child boxes + two child references) and triangle records (three
+// Woop rows + id/flags), in an order chosen at upload.  A child reference is the index of a record, with the sign bit set
+// when it points at a leaf (a run of consecutive triangle records ended by a "last" flag).  Every traversal step, inner
+// node or triangle, therefore is "fetch 64 B at recs + 64 * index, then compute", and a lane's traversal stack is a
+// column of an LDS array whose bottom slot holds the sentinel that ends the traversal.
 //
 // Two kernels produce bit-identical answers:
 //   k_extend_batch   one 64-ray batch per wave step, loop-per-phase traversal as in the reference;
@@ -21,6 +21,7 @@ namespace ptd {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+constexpr uint32_t kRefIndex = 0x3FFFFFFFu;      // record index of a reference (references to leaves are negative)
 constexpr int kStepsPerCheck = 2;                // traversal steps between two looks at the refill condition
 constexpr uint32_t kChunk = 128;                 // rays per chunk; chunk c belongs to wave c mod #waves
 // stream kernel: refill once this many lanes have no ray.  Measured on the 868 k-triangle stand-in, 78 M rays per launch
@@ -206,7 +207,7 @@ __device__ __forceinline__ void node_step(const DScene &sc, RayState &R, const S
     const int far_child = right_first ? cl : cr;
     if (both) stack_push(R, stk, far_child);
     if (!(hl || hr)) next = stack_pop(R, stk);
-    if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
+    if (COUNT && next < 0) R.c_leaves++;
     R.node = next;
 }
 
@@ -232,14 +233,14 @@ __device__ __forceinline__ void tri_step(const DScene &sc, RayState &R, const ST
         const float v = __fmaf_rn(t, Dy, Oy);
         if ((u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f)) {
             R.t = t;
-            R.hid = (uint32_t)R.node;
+            R.hid = (uint32_t)R.node & kRefIndex;
             if (KEEPN) R.hn = cross3(xyz(v11), xyz(v22));      // reference src/bvh.cuh:114
         }
     }
     int next = R.node + 1;
     if (flags & 1u) {
         next = stack_pop(R, stk);
-        if (COUNT && next != kSentinel && (uint32_t)next >= sc.first_tri) R.c_leaves++;
+        if (COUNT && next < 0) R.c_leaves++;
     }
     R.node = next;
 }
@@ -259,12 +260,12 @@ template <bool COUNT, bool CANON, class STK>
 __device__ __forceinline__ void traverse_phases(const DScene &sc, RayState &R, const STK &stk)
 {
     while (R.node != kSentinel) {
-        while ((uint32_t)R.node < sc.first_tri) {
+        while (R.node >= 0 && R.node != kSentinel) {
             const float4 *p = sc.recs + (size_t)R.node * 4;
             node_step<COUNT, CANON>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
-        while (R.node != kSentinel && (uint32_t)R.node >= sc.first_tri) {
-            const float4 *p = sc.recs + (size_t)R.node * 4;
+        while (R.node < 0) {
+            const float4 *p = sc.recs + (size_t)((uint32_t)R.node & kRefIndex) * 4;
             tri_step<COUNT, false>(sc, R, stk, p[0], p[1], p[2], p[3]);
         }
     }
@@ -296,13 +297,13 @@ template <bool COUNT, bool CANON, bool KEEPN, class STK>
 __device__ __forceinline__ void stream_step(const DScene &sc, RayState &R, const STK &stk)
 {
     if (R.node == kSentinel) return;
-    const float4 *p = sc.recs + (size_t)R.node * 4;
+    const float4 *p = sc.recs + (size_t)((uint32_t)R.node & kRefIndex) * 4;
     const float4 r0 = p[0], r1 = p[1], r2 = p[2];
     float4 r3 = p[3];
     // Keep the whole record one batch of loads issued here: without this the compiler sinks the loads of the child
     // references into the node branch, a second memory round trip in every step.
     asm volatile("" : "+v"(r3.x), "+v"(r3.y));
-    if ((uint32_t)R.node < sc.first_tri) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
+    if (R.node >= 0) node_step<COUNT, CANON>(sc, R, stk, r0, r1, r2, r3);
     else tri_step<COUNT, KEEPN>(sc, R, stk, r0, r1, r2, r3);
     // Keep the record address in registers of its own until the step is over.  When the allocator lets it share
     // registers with one of the four loaded values, the next step's address computation has to wait for every

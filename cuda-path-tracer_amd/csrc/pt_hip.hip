@@ -1005,44 +1005,45 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                 return fail(ctx, PT_ERR_ARG, "node %llu: %s", (unsigned long long)bad_node[part],
                             bad[part] == 1 ? "child out of range"
                                            : (bad[part] == 2 ? "leaf run leaves the triangle buffer" : "truncated triangle"));
-        // record index of every run: nodes first, then the record nothing can hit, then the runs in node order
-        // With the line-aware layout the two-triangle runs come first, each starting on an even record index, so that
-        // both records of such a leaf share one 128 B line; the other runs follow (no record is wasted either way).
+        // Where every record goes: nodes first, then the record nothing can hit, then the runs in node order.  With the
+        // line-aware layout the two-triangle runs come first, each on an even record index, so that both records of such
+        // a leaf share one 128 B line; the other runs follow (no record is wasted either way); inner nodes are paired,
+        // see node_layout_pairs.
         std::vector<uint64_t> run_at(2 * N);
+        std::vector<uint32_t> newid;
+        std::vector<uint64_t> holes;                      // records no reference points at
         uint64_t total_recs = N + 1;
+        const uint64_t nohit_at = N;
         if (ctx->node_layout == 1) {
-            total_recs += total_recs & 1;                                   // at most one unused record
+            if (total_recs & 1) { holes.push_back(total_recs); total_recs++; }      // at most one unused record
             for (uint64_t k = 0; k < 2 * N; k++)
                 if (run[k] == 2) { run_at[k] = total_recs; total_recs += 2; }
             for (uint64_t k = 0; k < 2 * N; k++)
                 if (run[k] != 2) { run_at[k] = total_recs; total_recs += run[k]; }
+            if (!node_layout_pairs(s->bvh_nodes, N, newid)) return fail(ctx, PT_ERR_ARG, "node graph is not a tree");
         } else {
             for (uint64_t k = 0; k < 2 * N; k++) { run_at[k] = total_recs; total_recs += run[k]; }
+            newid.resize(N);
+            for (uint64_t i = 0; i < N; i++) newid[i] = (uint32_t)i;
         }
+        holes.push_back(nohit_at);
         if (total_recs >= (1ull << 30)) return fail(ctx, PT_ERR_ARG, "mesh too large for 30-bit record references");
         HostArray<float4> recs(total_recs * 4);
         if (!recs.p) return fail(ctx, PT_ERR_NOMEM, "pt_scene_upload: out of host memory");
         {
-            float4 *nohit = recs.p + N * 4;
+            // the record nothing can hit stands in for empty leaves; the records the layout leaves unused are never
+            // referenced, but defined: copies of it
+            float4 nohit[4];
             nohit[0] = nohit[1] = nohit[2] = make_float4(0, 0, 0, 0);
             float4 meta = make_float4(0, 0, 0, 0);
             const uint32_t m[2] = {PT_PRIM_MISS, 3u};
             std::memcpy(&meta, m, 8);
             nohit[3] = meta;
-            // the record the alignment of the two-triangle runs may leave unused: never referenced, but defined
-            if (N + 2 <= total_recs) std::memcpy(recs.p + (N + 1) * 4, nohit, 64);
+            for (uint64_t h : holes) std::memcpy(recs.p + h * 4, nohit, 64);
         }
         std::vector<uint32_t> mesh_first;
         if (many_meshes)
             for (uint64_t k = 0; k < s->num_meshes; k++) mesh_first.push_back(s->meshes[k].first_face);
-        // where every inner node goes (see node_layout_pairs)
-        std::vector<uint32_t> newid;
-        if (ctx->node_layout == 1) {
-            if (!node_layout_pairs(s->bvh_nodes, N, newid)) return fail(ctx, PT_ERR_ARG, "node graph is not a tree");
-        } else {
-            newid.resize(N);
-            for (uint64_t i = 0; i < N; i++) newid[i] = (uint32_t)i;
-        }
         // Pass 2: node records with their child references rewritten, triangle records with id and flags
         parallel_chunks(N, bad.size(), [&](size_t, uint64_t lo, uint64_t hi) {
             for (uint64_t i = lo; i < hi; i++) {
@@ -1053,7 +1054,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                 for (int c = 0; c < 2; c++) {
                     if (ch[c] >= 0) { ch[c] = (int32_t)newid[ch[c]]; continue; }
                     const uint64_t count = run[2 * i + c];
-                    if (count == 0) { ch[c] = (int32_t)N; continue; }
+                    if (count == 0) { ch[c] = (int32_t)(0x80000000u | (uint32_t)nohit_at); continue; }
                     uint64_t a = (uint64_t)(uint32_t)~ch[c];
                     float4 *out = recs.p + run_at[2 * i + c] * 4;
                     for (uint64_t k = 0; k < count; k++, a += 3, out += 4) {
@@ -1067,7 +1068,7 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                         std::memcpy(&meta, m, 12);
                         out[3] = meta;
                     }
-                    ch[c] = (int32_t)run_at[2 * i + c];
+                    ch[c] = (int32_t)(0x80000000u | (uint32_t)run_at[2 * i + c]);      // sign bit: a leaf
                 }
                 std::memcpy(&node[3], ch, 8);
             }
@@ -1087,14 +1088,13 @@ int pt_scene_upload(pt_ctx *ctx, const pt_scene_desc *s)
                 int32_t ch[2];
                 std::memcpy(ch, &recs[(size_t)ni * 4 + 3], 8);
                 for (int c = 0; c < 2; c++)
-                    if ((uint64_t)ch[c] < N) st.push_back({(uint32_t)ch[c], dep + 1});
+                    if (ch[c] >= 0) st.push_back({(uint32_t)ch[c], dep + 1});
             }
             if (maxd > (uint32_t)kMaxTreeDepth)
                 return fail(ctx, PT_ERR_ARG, "BVH depth %u exceeds the %d-entry traversal stack", maxd, kMaxTreeDepth);
         }
         int rc;
         if ((rc = upload_raw(ctx, recs.p, total_recs * 4, &sc.recs)) != PT_OK) return rc;
-        sc.first_tri = (uint32_t)N;
         sc.stack_slots = maxd + 1;
         sc.has_bvh = 1;
         if (many_meshes) {
