@@ -318,6 +318,7 @@ def main():
         workload = {"scene": args.scene, "width": args.width, "height": args.height, "spp": args.spp}
         if args.scene == "synth":
             workload["instances"] = args.instances
+        out["config"]["workload_key"] = workload
         pfile = PROFILES.get(args.scene)
         if pfile and os.path.exists(os.path.join(ROOT, pfile)):
             cand = json.load(open(os.path.join(ROOT, pfile)))

@@ -93,9 +93,10 @@ int main(int argc, char **argv)
         st.rays += r.rays; st.paths += r.paths; st.iterations += r.iterations;
         st.ms_total = std::max(st.ms_total, r.ms_total);
     }
-    std::printf("{\"gpus\": %zu, \"rays\": %llu, \"paths\": %llu, \"iterations\": %llu, \"ms\": %.3f, \"mrays_per_s\": %.1f}\n",
+    std::printf("{\"gpus\": %zu, \"rays\": %llu, \"paths\": %llu, \"iterations\": %llu, \"ms\": %.3f, \"mrays_per_s\": %.1f, "
+                "\"render_mode\": %d}\n",
                 G, (unsigned long long)st.rays, (unsigned long long)st.paths, (unsigned long long)st.iterations, st.ms_total,
-                st.ms_total > 0 ? st.rays / st.ms_total / 1e3 : 0.0);
+                st.ms_total > 0 ? st.rays / st.ms_total / 1e3 : 0.0, pt_render_mode_used(ctx));
 
     if (const char *e = std::getenv("PT_PFM")) {        // PT_PFM=1: also dump the linear film as image_file.pfm
         if (e[0] == '1') {

@@ -17,6 +17,6 @@ passes=(
 i=0
 for p in "${passes[@]}"; do
   i=$((i+1))
-  timeout -s KILL 240 rocprofv3 --pmc $p --output-format csv -d $R/gpurun_out/$name/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $R/gpurun_out/$name/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $R/gpurun_out/$name/p$i.log; exit 1; }
+  timeout -s KILL 420 rocprofv3 --pmc $p --output-format csv -d $R/gpurun_out/$name/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $R/gpurun_out/$name/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $R/gpurun_out/$name/p$i.log; exit 1; }
 done
 python3 $R/tools/pmc_sum.py $R/gpurun_out/$name "$pat"
