@@ -24,8 +24,9 @@ The JSON line also carries
                 reduced-resolution run of the same scene, times the rays the launch traces) over the mean duration of the
                 non-empty extend launches.  The tree is served by L1 / L2 / Infinity Cache and launches of several streams
                 overlap, so that figure is NOT an HBM fraction and may exceed the peak; `record_rate` = the 64 B records
-                the launches fetch per second of extend time against the rate a bare dependent-gather probe reaches at the
-                same hit mix and lane occupancy (what really binds the kernel; at most 1).
+                the launches fetch per second of extend time, next to the rate a bare dependent-gather probe reaches at the
+                same cache-hit mix and number of fetching lanes (the unit that really binds the kernel is the CU's handling
+                of per-lane fetches that miss L1; the probe is a reference for it, not a bound).
   cpu_baseline  the CPU oracle (a host restatement of the reference's traversal and shading) timed on this machine's
                 cores on a bounded sample of the same workload (960x540, 320 spp).
   film_check    the film of the last timed frame: finite everywhere, and its mean next to the mean of the oracle's film
@@ -397,15 +398,16 @@ def main():
                 ceiling = None if not (counters and prof.get("probe_mixed_g_records_per_s")) else prof["probe_mixed_g_records_per_s"] * 1e9
                 roof["record_rate"] = {
                     "records_per_s": round(rate, 0),
-                    "probe_at_extend_mix_records_per_s": ceiling,
-                    "frac": None if not ceiling else round(rate / ceiling, 4),
-                    "extend_alone_records_per_s": prof.get("extend_alone_records_per_s") if counters else None,
-                    "extend_alone_frac": None if not (ceiling and prof.get("extend_alone_records_per_s"))
+                    # a reference rate, not a bound: the probe's fetches are uniformly random within its three sets
+                    "probe_at_kernel_mix_records_per_s": ceiling,
+                    "ratio_to_probe": None if not ceiling else round(rate / ceiling, 4),
+                    "kernel_alone_records_per_s": prof.get("extend_alone_records_per_s") if counters else None,
+                    "kernel_alone_ratio_to_probe": None if not (ceiling and prof.get("extend_alone_records_per_s"))
                     else round(prof["extend_alone_records_per_s"] / ceiling, 4),
                 }
             if counters:
                 roof["counters"] = {k: prof.get(k) for k in (
-                    "l2_hit_rate", "l1_hit_share", "fabric_share_of_records", "active_lane_fraction", "valu_busy",
+                    "l2_hit_rate", "l1_hit_share", "fabric_share_of_records", "active_lane_fraction",
                     "waves_waiting", "ta_busy", "extend_ms_per_frame_one_stream", "kernel_source_hash", "git_commit")}
             else:
                 roof["counters"] = None

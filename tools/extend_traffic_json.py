@@ -63,10 +63,12 @@ b = bench_line(os.path.join(src, "bench_default.log"))
 mode = b["config"]["render_mode"]
 kernel = "k_path_stream" if mode == 2 else "k_extend_stream"
 if mode == 2:
-    # one kernel, one stream: its time in the default run is its time alone
-    alone_ms, _ = kernel_total_ms(os.path.join(src, "kernel_stats.txt"), kernel)
-    frames_in_trace = b["steps"] + b["warmup"]
-    alone_src = "kernel_stats"
+    # one kernel, one stream: its time in the default run is its time alone; the bench line has it per timed frame (HIP
+    # events around the launches), the kernel-trace total also holds the untimed frames and the oracle-sized sample
+    alg = b["roofline"]["algorithmic"]
+    alone_ms = alg["avg_launch_ms"] * alg["launches"]
+    frames_in_trace = b["steps"]
+    alone_src = "bench_default"
 else:
     alone_ms, _ = kernel_total_ms(os.path.join(src, "kernel_stats_one_stream.txt"), kernel)
     one = bench_line(os.path.join(src, "bench_one_stream.log"))
@@ -122,14 +124,15 @@ out = {
     "fabric_share_of_records": round(f_fab, 4),
     "fabric_reads_per_record": round(c["TCC_EA0_RDREQ_sum"] / (c["TCP_TOTAL_CACHE_ACCESSES_sum"] / 4.0), 4),
     "active_lane_fraction": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
-    "valu_busy": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 4),
     "waves_waiting": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
     "ta_busy": round(c["TA_TA_BUSY_sum"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 4),
     "valu_insts_per_vmem_rd_inst": round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_VMEM_RD"], 2),
     "probe_g_records_per_s": {"l1_resident": r_l1, "l2_resident": r_l2, "infinity_cache_resident": r_fab},
     # the three rates chained one after the other (a ray's next fetch waits for this one)
     "record_rate_serial_model": round(1e9 / (f_l1 / r_l1 + f_l2 / r_l2 + f_fab / r_fab)),
-    # a bare dependent-gather loop with the kernel's own mix and lane occupancy (tools/gather_probe2 <lanes> <L1 %> <L2 %>)
+    # a bare dependent-gather loop with the kernel's own mix and fetching lanes (tools/gather_probe2 <lanes> <L1 %> <L2 %>,
+    # arguments from the counters by tools/probe_mix.py).  A reference rate, not a bound: the probe's fetches are uniformly
+    # random within each set, the kernel's are not.
     "probe_mixed_args": mixed_args,
     "probe_mixed_g_records_per_s": mixed,
     # records the kernel fetches per frame (node visits + triangle tests of the rays it traces) over its time alone

@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: tools/profile_round.sh <tag> <kernel> [bench args...]   (on the GPU box, from the repo root)
-#   kernel = k_extend_stream (workloads the library renders in wavefront mode) or k_path_stream (whole-path mode)
+# usage: tools/profile_round.sh <tag> [bench args...]   (on the GPU box, from the repo root)
+# The traversal kernel profiled is the one the library picks for the workload: k_extend_stream in wavefront mode,
+# k_path_stream in whole-path mode (config.render_mode of the first run's bench line).
 # 1. rocprofv3 --kernel-trace --stats of `bench.py <args>` (with the CPU leg: it counts the per-ray traversal means);
 # 2. wavefront mode only: the same with one stream (extend launches not overlapped by anything);
 # 3. the counter passes of tools/pmc_passes.sh; 4. the dependent-gather probes, the second at the kernel's measured mix.
 # Everything lands in gpurun_out/<tag>/; tools/extend_traffic_json.py turns it into the summary bench.py reads.
-tag=$1; kern=$2; shift 2
+tag=$1; shift
 R=$PWD
 mkdir -p $R/gpurun_out/$tag
 export TMPDIR=/tmp
@@ -14,6 +15,9 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 python3 $R/tools/kstats.py $R/gpurun_out/$tag/stats > $R/gpurun_out/$tag/kernel_stats.txt
 rm -rf $R/gpurun_out/$tag/stats
 cat $R/gpurun_out/$tag/kernel_stats.txt
+kern=k_extend_stream
+grep -q '"render_mode": 2' $R/gpurun_out/$tag/bench_default.log && kern=k_path_stream
+echo "traversal kernel: $kern"
 if [ "$kern" = "k_extend_stream" ]; then
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/stats1 -- python3 $R/bench.py --no-cpu-baseline --tune 9=1 "$@" > $R/gpurun_out/$tag/bench_one_stream.log 2>&1 || { echo "one-stream stats run failed"; tail -5 $R/gpurun_out/$tag/bench_one_stream.log; exit 1; }
   python3 $R/tools/kstats.py $R/gpurun_out/$tag/stats1 > $R/gpurun_out/$tag/kernel_stats_one_stream.txt
