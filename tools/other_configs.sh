@@ -11,6 +11,8 @@ run --scene bunny --spp 512 --steps 2 --warmup 1
 run --scene city --spp 2048 --steps 2 --warmup 1
 run --scene city --spp 256 --steps 4 --warmup 1
 run --scene synth --instances 116 --width 3840 --height 2160 --spp 128 --steps 2 --warmup 1
+run --scene dragon_dense --spp 512 --steps 2 --warmup 1
+run --scene dragon_dense --spp 64 --steps 6 --warmup 2 --no-cpu-baseline
 run --spp 64 --steps 20 --warmup 3 --no-cpu-baseline
 run --spp 128 --steps 10 --warmup 2 --no-cpu-baseline
 run --spp 256 --steps 6 --warmup 2 --no-cpu-baseline
