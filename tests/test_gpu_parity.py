@@ -299,17 +299,20 @@ def test_4k_frame_in_three_slabs(pkg, ctx):
     print("4K x %d spp: one slab %.1f ms, three slabs %.1f ms" % (spp, one.ms_total, three.ms_total))
 
 
-@pytest.mark.parametrize("name", ["dragon", "bunny"])
+@pytest.mark.parametrize("name", ["dragon", "bunny", "dragon_dense", "city"])
 def test_benchmark_scene_files_at_full_size(pkg, ctx, name):
-    """(c) 1920x1080 at 2 spp, the benchmark's frame size: every path started once, the film finite and non-negative
-    (a 0/0 from reference src/render.cu:145-151 would show here), the samples split over two calls equal to one call up to
-    float addition order, and the ray count the sum over both halves."""
+    """(c) 1920x1080 at 2 spp, the benchmark's frame size: every path started once, film and ray count bit-equal to the
+    oracle's, the film finite and non-negative (a 0/0 from reference src/render.cu:145-151 would show here), the samples split
+    over two calls equal to one call up to float addition order, and the ray count the sum over both halves."""
     W, H, spp = 1920, 1080, 2
     scene = pkg.HostScene(S.scene_file(pkg, name), W, H)
     ctx.upload(scene)
     ctx.film_bind(W, H)
     st = ctx.render(0, spp, spp, seed=1)
     full = ctx.film_download()
+    ofilm, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=1, nthreads=16)
+    assert st.rays == ost.rays
+    assert_same_film(full, ofilm, "%s 1920x1080" % name)
     assert st.paths == W * H * spp
     assert np.isfinite(full).all() and (full >= 0).all()
     assert full.mean() > 1e-3
