@@ -88,6 +88,18 @@ def launch_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    try:
+        return wait_for_ranks(procs)
+    except BaseException:
+        # interrupted: the ranks (this process's own children, by their process ids) do not outlive it
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+
+
+def wait_for_ranks(procs):
+    n = len(procs)
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()

@@ -145,3 +145,54 @@ def test_no_alloc_entry_point_on_deep_trees(pkg, ctx):
         else:
             with pytest.raises(pkg.PtError, match="stack slots"):
                 _run(ctx.intersect_device_noalloc, o4, d4)
+
+
+def test_no_alloc_entry_point_under_stream_capture(pkg, ctx):
+    """The queued form (stats == NULL) inside a HIP stream capture of the context's stream: the capture takes the call (it
+    allocates nothing, copies nothing back and waits for nothing), and launching the captured graph gives the answers of the
+    synchronous form."""
+    import ctypes as C
+
+    import torch
+
+    hip = C.CDLL("libamdhip64.so")          # the runtime already in the process (torch loaded it)
+    for f in ("hipStreamBeginCapture", "hipStreamEndCapture", "hipGraphInstantiate", "hipGraphLaunch", "hipStreamSynchronize",
+              "hipGraphExecDestroy", "hipGraphDestroy"):
+        getattr(hip, f).restype = C.c_int
+    g = np.load(os.path.join(S.GOLDEN, "rays_knot.npz"))
+    ctx.upload(S.parity_cases(pkg)["knot"])
+    o4, d4 = _device_rays(np.tile(g["org"], (8, 1)), np.tile(g["dir"], (8, 1)))
+    n = o4.shape[0]
+    hit = torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda")
+    t = torch.full((n,), -7.0, dtype=torch.float32, device="cuda")
+    # one ordinary call first: a kernel's first launch loads its code object, which is not a thing to do under capture
+    ctx.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr())
+    hit.fill_(-7.0)
+    t.fill_(-7.0)
+    torch.cuda.synchronize()
+    stream = C.c_void_p(ctx.stream)
+    graph, gexec = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamBeginCapture(stream, 2) == 0                       # hipStreamCaptureModeRelaxed
+    try:
+        ctx.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr(), want_stats=False)
+    finally:
+        rc = hip.hipStreamEndCapture(stream, C.byref(graph))
+    assert rc == 0 and graph.value, "the capture was refused or invalidated (%d)" % rc
+    torch.cuda.synchronize()
+    assert (t.cpu().numpy() == -7.0).all(), "the call ran instead of being captured"
+    assert hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)) == 0
+    try:
+        for _ in range(2):                                                  # a graph is there to be launched repeatedly
+            hit.fill_(-7.0)
+            t.fill_(-7.0)
+            torch.cuda.synchronize()
+            assert hip.hipGraphLaunch(gexec, stream) == 0
+            assert hip.hipStreamSynchronize(stream) == 0
+            assert np.array_equal(t.cpu().numpy(), np.tile(g["t"], 8))
+            assert np.array_equal(hit.cpu().numpy()[:, 3].view(np.uint32), np.tile(g["prim"], 8))
+    finally:
+        hip.hipGraphExecDestroy(gexec)
+        hip.hipGraphDestroy(graph)
+    # and the context is usable afterwards
+    st = ctx.intersect_device_noalloc(n, o4.data_ptr(), d4.data_ptr(), hit.data_ptr(), t.data_ptr())
+    assert st.rays == n and np.array_equal(t.cpu().numpy(), np.tile(g["t"], 8))
