@@ -591,6 +591,50 @@ def test_bench_starts_its_own_ranks(pkg):
     assert abs(two["film_check"]["mean"] - one["film_check"]["mean"]) <= 1e-5 * one["film_check"]["mean"]
 
 
+def test_film_reduce_through_torch_rccl_backend(pkg, tmp_path):
+    """The collective of the one-process-per-GPU form is torch.distributed's reduce on the film tensor the library renders
+    into, backend "nccl" (RCCL).  One GPU allows one rank: a one-rank group, the reduce in place.  Checks what a single GPU
+    can: the process group comes up beside the library (both bind the HIP runtime PyTorch brought), the reduce runs on the
+    tensor the library wrote through its own streams, and the film is the one rendered without it."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "one_rank.py"
+    script.write_text("""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import __graft_entry__ as G
+import scenes as S
+pkg = G.load_package()
+import cuda_path_tracer_amd.distributed as D
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%%d" %% (29600 + os.getpid() %% 300), rank=0, world_size=1)
+W, H, spp = 96, 64, 6
+ctx = pkg.Context(0)
+ctx.upload(S.knot_scene(pkg, W, H))
+film = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+ctx.film_bind(W, H, film.data_ptr())
+torch.cuda.synchronize()
+D.render_and_reduce(lambda b, c, t, s: ctx.render(b, c, t, s), film, spp, seed=3)
+dist.reduce(film, dst=0, op=dist.ReduceOp.SUM)
+torch.cuda.synchronize()
+np.save(sys.argv[1], film.cpu().numpy())
+ctx.close()
+dist.destroy_process_group()
+""" % (root, root))
+    out = str(tmp_path / "film.npy")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(script), out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    W, H, spp = 96, 64, 6
+    scene = S.knot_scene(pkg, W, H)
+    ofilm, _ = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=3)
+    assert_same_film(np.load(out), ofilm, "film after a one-rank RCCL reduce")
+
+
 def test_render_is_partition_invariant(pkg, ctx):
     """Samples split over two calls (as two GPUs would) sum to the single-call film up to float addition order."""
     W, H, spp = 96, 64, 8
