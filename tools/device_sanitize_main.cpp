@@ -54,6 +54,14 @@ int main()
         MUST(pt_set_option(ctx, PT_OPT_POOL_SIZE, streams == 2 ? 1024 : (1u << 20)));
         MUST(pt_render(ctx, 0, 5, 5, 3, &st));
     }
+    // both render modes explicitly, then the mode chosen from the first sample (after an upload forgets the choice)
+    for (uint64_t mode : {1, 2, 0}) {
+        MUST(pt_set_option(ctx, PT_OPT_RENDER_MODE, mode));
+        if (mode == 0) { MUST(pt_scene_upload(ctx, &good)); MUST(pt_film_bind(ctx, W, H, nullptr)); }
+        MUST(pt_render(ctx, 0, 5, 5, 3, &st));
+        MUST(pt_render(ctx, 2, 1, 5, 3, &st));
+        std::printf("render mode %llu -> ran in mode %d\n", (unsigned long long)mode, pt_render_mode_used(ctx));
+    }
     MUST(pt_set_option(ctx, PT_OPT_SLAB_BYTES, 1u << 20));          // several slabs
     MUST(pt_render(ctx, 0, 40, 40, 3, &st));
     MUST(pt_film_download(ctx, film.data()));
