@@ -6,9 +6,12 @@
 //   mode 3  structure of arrays: the record's four 16 B parts live in four arrays (part c of record i at c * records + i),
 //           so a lane's four loads go to four different cache lines
 // Every lane walks a pseudo-random chain: next index = hash(sum of the record's words) so loads depend on each other.
-// usage: gather_probe [records] [steps] [lds_bytes_per_block] [active_lanes]
+// usage: gather_probe [records] [steps] [lds_bytes_per_block] [active_lanes] [placement]
 // active_lanes < 64 (mode 0 only): the other lanes of every wave sit out (exec-masked), as lanes without a ray do in the
 // traversal kernel; the rate then tells whether the fetch path is priced per instruction or per active lane.
+// placement: 0 (default) the first active_lanes lanes of the wave fetch; 1 a pseudo-random subset of about that size, spread
+// over the whole wave; 2 the first active_lanes / 2 lanes of each half-wave; 3 every lane whose index modulo 64 / active_lanes
+// is 0 (a regular stride).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,14 +59,18 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], uint32_t lane)
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_probe(const float4 *__restrict__ recs, uint32_t nrec, int steps, uint32_t *out,
-                                               uint32_t active)
+                                               uint32_t active, int placement = 0)
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t idx = mix(gid) % nrec;
     uint32_t acc = 0;
     if (lds[threadIdx.x] == 12345) acc = 1;      // keep the LDS allocation
-    if (MODE == 0 && lane >= active) { out[gid] = 0; return; }
+    bool on = lane < active;
+    if (placement == 1) on = (mix(lane * 2654435761u + (threadIdx.x >> 6)) & 63u) < active;
+    if (placement == 2) on = (lane & 31u) < active / 2;
+    if (placement == 3) on = active >= 64 || (lane % (64u / active)) == 0;
+    if (MODE == 0 && !on) { out[gid] = 0; return; }
     for (int s = 0; s < steps; s++) {
         float4 r[4];
         if (MODE == 0) {
@@ -107,6 +114,7 @@ int main(int argc, char **argv)
     const int steps = argc > 2 ? atoi(argv[2]) : 2000;
     const int lds_bytes = argc > 3 ? atoi(argv[3]) : 26 * 1024;
     const uint32_t active = argc > 4 ? atoi(argv[4]) : 64;
+    const int placement = argc > 5 ? atoi(argv[5]) : 0;
     std::vector<uint32_t> h((size_t)nrec * 16);
     uint32_t s = 1;
     for (auto &v : h) { s = s * 1664525u + 1013904223u; v = s; }
@@ -121,7 +129,7 @@ int main(int argc, char **argv)
     for (int mode = 0; mode < (active < 64 ? 1 : 4); mode++) {
         for (int rep = 0; rep < 2; rep++) {
             CHECK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
+            if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active, placement);
             if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
             if (mode == 3) hipLaunchKernelGGL(k_probe<3>, dim3(blocks), dim3(256), lds_bytes, 0, recs, nrec, steps, out, active);
