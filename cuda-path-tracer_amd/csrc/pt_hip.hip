@@ -126,8 +126,14 @@ struct pt_ctx {
     double auto_settled = 0;   // the share of settled rays it was made on
     int last_mode = 0;         // mode the last pt_render call ran in
     int path_waves = 0;        // k_path_stream: cap on resident waves per CU (0: as many as fit)
-    int path_refill = 44;      // k_path_stream: service once this many lanes wait for it
-    int path_lds_slots = 32;   // k_path_stream: traversal stack slots per lane kept in LDS
+    // k_path_stream: service once this many lanes wait for it.  Measured on MI355X, ms per frame at 44 / 48 / 52 / 56: dense
+    // stand-in (128 spp) 182.1 / 181.1 / 181.3 / 184.5, city (256 spp) 95.4 / 94.2 / 93.4 / 93.7, 100.7 M triangles
+    // (3840x2160x32) 346 / 339.8 / 336.3 / 335.2.
+    int path_refill = 52;
+    // k_path_stream: traversal stack slots per lane kept in LDS (256 B per slot and wave).  28 and not the 32 that would
+    // fill the 160 KB of a CU with the 20 waves the registers allow: with all of the LDS taken the 100.7 M-triangle frame
+    // (a tree that needs 35 slots) is 4 % slower (336.8 ms against 323.4 - 323.8 with 16 to 28 slots).
+    int path_lds_slots = 28;
     PathCounters *pcnt = nullptr, *h_pcnt = nullptr;   // k_path_stream's counters, device and pinned host
     int *gstk = nullptr;           // overflow stack of the closest-hit entry points
     size_t gstk_threads = 0;
@@ -635,6 +641,9 @@ static int paths_run(pt_ctx *ctx, uint64_t first, uint64_t count_s, float4 *rows
     HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kPathBlock, shmem));
     if (per_cu < 1) return fail(ctx, PT_ERR_HIP, "pt_render: the path kernel does not fit a CU (%zu B of LDS)", shmem);
     if (ctx->path_waves > 0) per_cu = std::min(per_cu, ctx->path_waves);
+    if (std::getenv("PT_DEBUG"))
+        std::fprintf(stderr, "[pt] k_path_stream: %d waves per CU, %d stack slots in LDS%s, tree needs %u\n", per_cu, lds_slots,
+                     overflow ? ", overflow to global" : "", need);
     const uint32_t cps = (npix + kPathChunk - 1) / kPathChunk;
     if ((uint64_t)cps * count_s >= 0xFFFF0000ull) return fail(ctx, PT_ERR_ARG, "pt_render: sample slab too large");
     const uint32_t total_chunks = (uint32_t)(cps * count_s);

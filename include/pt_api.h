@@ -157,9 +157,9 @@ typedef struct pt_ctx pt_ctx;
                                        fewer than 42 % of that sample's rays are settled where they are made (nothing below
                                        the BVH root can stop them), else mode 1.  The film does not depend on the mode. */
 #define PT_OPT_TUNE_PATH_WAVES  14  /* render mode 2 tuning: cap on resident waves per CU (0 = as many as fit, default) */
-#define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 44) */
-#define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS; deeper entries go to a
-                                       global array */
+#define PT_OPT_TUNE_PATH_REFILL 15  /* render mode 2 tuning: a wave shades / restarts its lanes once this many wait (default 52) */
+#define PT_OPT_TUNE_PATH_LDS_SLOTS 16 /* render mode 2 tuning: traversal stack slots per lane kept in LDS (default 28); deeper
+                                       entries go to a global array */
 #define PT_OPT_SLAB_BYTES       4   /* device bytes the per-path contribution slab may take (default 32 GiB);
                                        samples beyond it are rendered slab after slab */
 

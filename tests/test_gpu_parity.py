@@ -915,8 +915,8 @@ def test_whole_path_kernel_matches_oracle(pkg, ctx, name):
             assert (st.nodes, st.tris, st.leaves) == (ost.nodes, ost.tris, ost.leaves) == (wst.nodes, wst.tris, wst.leaves), what
     finally:
         ctx.set_option(pkg.OPT_RENDER_MODE, 0)
-        ctx.set_option(pkg.OPT_TUNE_PATH_REFILL, 44)
-        ctx.set_option(pkg.OPT_TUNE_PATH_LDS_SLOTS, 32)
+        ctx.set_option(pkg.OPT_TUNE_PATH_REFILL, 52)
+        ctx.set_option(pkg.OPT_TUNE_PATH_LDS_SLOTS, 28)
         ctx.set_option(pkg.OPT_COUNT_TRAVERSAL, 0)
 
 
