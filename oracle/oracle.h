@@ -11,8 +11,11 @@
  * known-answer vectors; (2) the BVH builder/flattener against the node,
  * triangle-buffer and leaf counts recorded from the reference's own builder
  * for its four shipped meshes (reference src/bvh.cu:298,302) -- the FNV-1a-64
- * hashes recorded with those counts could NOT be reproduced, so the buffer
- * contents themselves are unpinned; (3) traversal + triangle test against an
+ * hashes recorded with those counts could NOT be reproduced; the buffer
+ * contents are pinned instead by a six-triangle tree worked out by hand from
+ * the text of reference src/bvh.cu:100-207,234-294 (tests/golden/
+ * bvh_handworked.npz, derivation in tools/make_golden_bvh_handworked.py), which
+ * the builder here reproduces byte for byte; (3) traversal + triangle test against an
  * independent float64 brute force; (4) the RGBE pixel decode against the
  * reference's own vendored reader (stb_image, compiled from the reference
  * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz).
