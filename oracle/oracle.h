@@ -16,7 +16,8 @@
  * the text of reference src/bvh.cu:100-207,234-294 (tests/golden/
  * bvh_handworked.npz, derivation in tools/make_golden_bvh_handworked.py), which
  * the builder here reproduces byte for byte; (3) traversal + triangle test against an
- * independent float64 brute force; (4) the RGBE pixel decode against the
+ * independent float64 brute force and against closest hits worked out by
+ * hand (tests/scenes.py, handworked_hits); (4) the RGBE pixel decode against the
  * reference's own vendored reader (stb_image, compiled from the reference
  * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz).
  * sin / cos / atan2 / acos / x^5 of the shading path are evaluated by fixed polynomial kernels (stated here and,

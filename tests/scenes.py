@@ -459,6 +459,57 @@ def chain_rays(levels, n=4096, seed=0):
     return org, d.astype(np.float32)
 
 
+def handworked_hits(pkg):
+    """A scene whose closest hits follow by hand, and rays with their answers (t, primitive id, unit normal), all exact in
+    binary floating point.  The mesh is the six unit right triangles of tests/golden/bvh_handworked.npz (triangle k spans
+    x in [a_k, a_k + 1], y in [0, 1] below the diagonal x - a_k + y <= 1, in the plane z = 1; a = 9, 0, 2, 12, 1, 10), over a
+    plane z = -2 (normal +z) and a sphere of radius 0.5 at (4.5, 0.25, 0).
+    Rays at the mesh have the direction (2^-10, 2^-10, +-1) -- not of unit length, which the triangle and plane tests do not
+    ask for -- and start 2^-9 short of the point aimed at in x and y, so that they arrive there at t = 2, every product and sum
+    on the way exact: with the Woop rows (0, 0, 1, 1), (1, 0, 0, -a), (0, 1, 0, 0) of these triangles (reference src/bvh.cu:214-227)
+    t = (1 - o.z) / d.z, u = o.x - a + t d.x, v = o.y + t d.y (src/bvh.cuh:93-120).
+      aimed at (a_k + 0.25, 0.25, 1): u = v = 0.25 -> triangle k at t = 2, normal cross(row x, row y) = (0, 0, 1), never flipped
+        towards the ray (src/bvh.cuh:114), from below (z = -1) and from above (z = 3) alike;
+      aimed at (a_k + 0.75, 0.75, 1): u + v = 1.5 -> not in the triangle: from below nothing else lies ahead (a miss), from above
+        the plane at t = 5 (src/object.cuh:62-75).
+    Rays exactly along +-z (unit length):  at x = 4.5, y = 0.25 the sphere, from below at t = 1 - 0.5, normal (0, 0, -1), from
+    above at t = 3 - 0.5, normal (0, 0, 1) (src/object.cuh:27-44);  at x = 6.5, a gap of the mesh, nothing from below and the
+    plane at t = 5 from above.  And the reference's treatment of axis-parallel rays at the mesh: with d.x = 0 its slab test
+    forms x0 * inf - o.x * inf = NaN (src/bvh.cuh:79-80,136-137), which its integer min / max order above every number
+    (src/bvh.cuh:18-27), so both boxes under the root are missed and the ray passes THROUGH triangle k: from below at
+    (a_k + 0.25, 0.25) a miss, from above the plane at t = 5."""
+    g = np.load(os.path.join(GOLDEN, "bvh_handworked.npz"))
+    a = [9.0, 0.0, 2.0, 12.0, 1.0, 10.0]
+    bvh = pkg.bvh_build(g["verts"])
+    cam = pkg.camera_make((6, 0.5, 12), (6, 0.5, 0), 40.0, 1.5, 0.0, 12.0)
+    tex, marg, cond = small_env(pkg)
+    planes = [pkg.make_plane((0, 0, -2), (0, 0, 1), (0.5, 0.5, 0.5, 0.0), pkg.DIFFUSE)]
+    spheres = [pkg.make_sphere((4.5, 0.25, 0.0), 0.5, (0.5, 0.5, 0.5, 0.0), pkg.MIRROR)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes, spheres=spheres, bvh=bvh,
+                            mesh_material=(0.6, 0.6, 0.6, 0.0), mesh_material_type=pkg.DIFFUSE)
+    PLANE, SPHERE, MISS = 0x80000000, 0x40000000, 0xFFFFFFFF
+    FLT_MAX = np.float32(3.402823466e38)
+    e = 2.0 ** -10
+    rays = []                                            # origin, direction, t, prim, normal
+    for k, ak in enumerate(a):
+        for z0, dz in ((-1.0, 1.0), (3.0, -1.0)):
+            rays.append(((ak + 0.25 - 2 * e, 0.25 - 2 * e, z0), (e, e, dz), 2.0, k, (0, 0, 1)))
+        rays.append(((ak + 0.75 - 2 * e, 0.75 - 2 * e, -1.0), (e, e, 1.0), FLT_MAX, MISS, (0, 0, 0)))
+        rays.append(((ak + 0.75 - 2 * e, 0.75 - 2 * e, 3.0), (e, e, -1.0), 5.0, PLANE | 0, (0, 0, 1)))
+        rays.append(((ak + 0.25, 0.25, -1.0), (0, 0, 1), FLT_MAX, MISS, (0, 0, 0)))           # axis-parallel: through the mesh
+        rays.append(((ak + 0.25, 0.25, 3.0), (0, 0, -1), 5.0, PLANE | 0, (0, 0, 1)))
+    rays.append(((4.5, 0.25, -1), (0, 0, 1), 0.5, SPHERE | 0, (0, 0, -1)))
+    rays.append(((4.5, 0.25, 3), (0, 0, -1), 2.5, SPHERE | 0, (0, 0, 1)))
+    rays.append(((6.5, 0.25, -1), (0, 0, 1), FLT_MAX, MISS, (0, 0, 0)))
+    rays.append(((6.5, 0.25, 3), (0, 0, -1), 5.0, PLANE | 0, (0, 0, 1)))
+    org = np.array([r[0] for r in rays], dtype=np.float32)
+    dir_ = np.array([r[1] for r in rays], dtype=np.float32)
+    t = np.array([r[2] for r in rays], dtype=np.float32)
+    prim = np.array([r[3] for r in rays], dtype=np.uint32)
+    nrm = np.array([r[4] for r in rays], dtype=np.float32)
+    return scene, org, dir_, t, prim, nrm
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

@@ -145,6 +145,17 @@ def test_bvh_builders_reproduce_the_handworked_tree(pkg):
         assert (b["num_tris"], b["num_leaves"]) == (6, 4), what
 
 
+def test_oracle_reproduces_handworked_hits(pkg):
+    """Closest hits that follow by hand (tests/scenes.py::handworked_hits: unit triangles in z = 1, a plane, a sphere, rays
+    along +-z; every t, id and normal exact): the oracle returns exactly them."""
+    scene, org, dir_, t, prim, nrm = S.handworked_hits(pkg)
+    ot, oprim, onrm, _ = O.intersect(S.as_oracle_desc(scene), org, dir_, want_normals=True)
+    assert np.array_equal(oprim, prim)
+    assert np.array_equal(ot, t)
+    hit = prim != 0xFFFFFFFF
+    assert np.array_equal(onrm[hit], nrm[hit])
+
+
 def test_host_bvh_parallel_build_equals_serial(pkg):
     """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
     bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""

@@ -74,6 +74,23 @@ def test_instanced_stress_scene_matches_oracle(pkg, ctx):
     assert_same_film(film, ofilm, "instanced")
 
 
+def test_device_reproduces_handworked_hits(pkg, ctx):
+    """Closest hits that follow by hand (tests/scenes.py::handworked_hits), not from the oracle: the device returns exactly
+    those distances, ids and normals, with both traversal kernels."""
+    scene, org, dir_, t, prim, nrm = S.handworked_hits(pkg)
+    ctx.upload(scene)
+    try:
+        for mode in (2, 1):
+            ctx.set_option(pkg.OPT_EXTEND_MODE, mode)
+            gt, gprim, gnrm = ctx.intersect(org, dir_, want_normals=True)
+            assert np.array_equal(gprim, prim), mode
+            assert np.array_equal(gt, t), mode
+            hit = prim != O.PRIM_MISS
+            assert np.array_equal(gnrm[hit], nrm[hit]), mode
+    finally:
+        ctx.set_option(pkg.OPT_EXTEND_MODE, 2)
+
+
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
     """The loop-per-phase batch kernel and the persistent single-step kernel must agree bit for bit with the fixture."""
     scene = S.parity_cases(pkg)["knot"]
