@@ -510,6 +510,28 @@ def handworked_hits(pkg):
     return scene, org, dir_, t, prim, nrm
 
 
+def handworked_film(pkg, width=32, height=16):
+    """A scene whose film follows by hand: a pinhole camera at (0, 1, 0) looking horizontally, a mirror plane y = 0 of albedo
+    (0.5, 0.25, 0.75), a one-texel environment of radiance e = (2, 1, 0.5).  A camera ray that goes up leaves the scene: its
+    pixel gets e.  One that goes down hits the mirror (reference src/render.cu:195-211: throughput x albedo, direction
+    reflected upwards) and then leaves: its pixel gets albedo x e = (1, 0.25, 0.375).  A one-texel map returns its texel for
+    every direction (the bilinear weights multiply differences that are zero), the values are dyadic, and every sample of a
+    pixel contributes the same value divided by a power-of-two sample count, so the sums are exact whatever the jitter --
+    except in the two pixel rows next to the horizon, where the jitter decides which side a sample falls on.
+    Returns (scene, expected film with NaN in the two horizon rows)."""
+    cam = pkg.camera_make((0, 1, 0), (0, 1, -1), 60.0, width / height, 0.0, 1.0)
+    tex = np.zeros((1, 1, 4), dtype=np.float32)
+    tex[0, 0] = [2.0, 1.0, 0.5, 1.0]
+    marg, cond = pkg.env_build(tex)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (0.5, 0.25, 0.75, 0.0), pkg.MIRROR)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes)
+    film = np.empty((height, width, 3), dtype=np.float32)
+    film[:height // 2 - 1] = [2.0, 1.0, 0.5]                  # row 0 is the top of the image
+    film[height // 2 - 1:height // 2 + 1] = np.nan
+    film[height // 2 + 1:] = [1.0, 0.25, 0.375]
+    return scene, film
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

@@ -156,6 +156,18 @@ def test_oracle_reproduces_handworked_hits(pkg):
     assert np.array_equal(onrm[hit], nrm[hit])
 
 
+def test_oracle_reproduces_handworked_film(pkg):
+    """A film that follows by hand (tests/scenes.py::handworked_film: pinhole camera, mirror plane, one-texel environment):
+    sky pixels hold the environment's radiance, floor pixels albedo times it, exactly, at 1, 4 and 64 samples per pixel."""
+    scene, want = S.handworked_film(pkg)
+    known = ~np.isnan(want)
+    H, W = want.shape[:2]
+    for spp in (1, 4, 64):
+        film, st = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=spp)
+        assert np.array_equal(film[known], want[known]), spp
+        assert st.paths == W * H * spp and st.paths < st.rays <= 2 * st.paths
+
+
 def test_host_bvh_parallel_build_equals_serial(pkg):
     """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
     bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""

@@ -91,6 +91,27 @@ def test_device_reproduces_handworked_hits(pkg, ctx):
         ctx.set_option(pkg.OPT_EXTEND_MODE, 2)
 
 
+def test_device_reproduces_handworked_film(pkg, ctx):
+    """A film that follows by hand (tests/scenes.py::handworked_film), not from the oracle: the device's film holds exactly
+    the environment's radiance in the sky pixels and albedo times it in the mirror floor's, in both render modes."""
+    scene, want = S.handworked_film(pkg)
+    known = ~np.isnan(want)
+    H, W = want.shape[:2]
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    try:
+        for mode in (1, 2, 0):
+            ctx.set_option(pkg.OPT_RENDER_MODE, mode)
+            for spp in (1, 4, 64):
+                ctx.film_clear()
+                st = ctx.render(0, spp, spp, seed=spp)
+                film = ctx.film_download()
+                assert np.array_equal(film[known], want[known]), (mode, spp)
+                assert st.paths == W * H * spp
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
+
+
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
     """The loop-per-phase batch kernel and the persistent single-step kernel must agree bit for bit with the fixture."""
     scene = S.parity_cases(pkg)["knot"]
