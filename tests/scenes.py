@@ -532,6 +532,74 @@ def handworked_film(pkg, width=32, height=16):
     return scene, film
 
 
+def furnace_cases(pkg):
+    """Scenes whose converged film is known from radiometry alone, not from any restatement of the reference: name ->
+    (scene, film width, film height, expected mean colour).  Every pixel of each looks at one convex Lambertian, glossy or
+    mirror surface that sees nothing but the environment, so a path is camera -> surface -> sky.
+      "sky over a plane": a Lambertian plane y = 0 of albedo rho under a smooth, non-uniform sky L(w): every pixel converges to
+        rho / pi x the integral of L(w) w.y over the upper hemisphere, here taken in float64 on a 2048 x 8192 midpoint grid.
+      the others: a constant sky L (64 x 32 texels, so the light sampler and its pdf are in play) around a unit sphere or a
+        convex 960-triangle mesh: Lambertian rho L; mirror rho L (reference src/render.cu:195-211); glossy (0.05 + 0.95 rho) L,
+        the 5 % mirror branch leaving the throughput alone (src/render.cu:164-193).
+    The reference's estimator (one-sample mix of cosine and light sampling, src/render.cu:129-162) is unbiased up to its light
+    sampler, which draws texel-grid directions from two quantile tables of W and H entries (src/environment_map.cu:107-125,
+    src/environment_map.cuh:39-49): that costs up to 0.4 % here, so the tests allow 1 %."""
+    def sky(d):
+        s = np.array([0.3, 0.8, 0.5]) / np.linalg.norm([0.3, 0.8, 0.5])
+        return 0.6 + 0.4 * d[..., 0] + 1.5 * np.maximum(d @ s, 0.0) ** 8
+
+    def dirs(theta, phi):
+        T, P = np.meshgrid(theta, phi, indexing="ij")
+        return np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], -1), T
+
+    tint = np.array([1.0, 0.7, 0.4])
+    rho = np.array([0.8, 0.5, 0.3])
+    mat = (0.8, 0.5, 0.3, 0.0)
+    cases = {}
+    # texel (row r, column c) is looked up at theta = (r + 0.5) pi / H from +y and atan2(z, x) = ((c + 0.5) / W - 0.5) 2 pi
+    # (reference src/environment_map.cuh:32-37)
+    W, H = 256, 128
+    d, _ = dirs((np.arange(H) + 0.5) * np.pi / H, ((np.arange(W) + 0.5) / W - 0.5) * 2 * np.pi)
+    tex = np.zeros((H, W, 4), dtype=np.float32)
+    tex[..., :3] = sky(d)[..., None] * tint
+    marg, cond = pkg.env_build(tex)
+    n = 2048
+    d, T = dirs((np.arange(n) + 0.5) * (np.pi / 2) / n, (np.arange(4 * n) + 0.5) * 2 * np.pi / (4 * n))
+    integral = (sky(d) * np.sin(T) * np.cos(T)).sum() * (np.pi / 2 / n) * (2 * np.pi / (4 * n))
+    cam = pkg.camera_make((0, 1, 0), (0, 0, -1), 30.0, 2.0, 0.0, 1.0)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), mat, pkg.DIFFUSE)]
+    cases["sky over a plane"] = (pkg.ManualScene(cam, tex, marg, cond, planes=planes), 32, 16, rho * tint * integral / np.pi)
+
+    L = np.array([2.0, 1.0, 0.5])
+    tex = np.zeros((32, 64, 4), dtype=np.float32)
+    tex[..., :3] = L
+    marg, cond = pkg.env_build(tex)
+    cam = pkg.camera_make((0, 0, 4), (0, 0, 0), 10.0, 2.0, 0.0, 4.0)      # the whole film lies inside the silhouette
+    for kind, typ, want in (("lambertian", pkg.DIFFUSE, rho * L), ("mirror", pkg.MIRROR, rho * L),
+                            ("glossy", pkg.GLOSSY, (0.05 + 0.95 * rho) * L)):
+        spheres = [pkg.make_sphere((0, 0, 0), 1.0, mat, typ)]
+        cases[kind + " sphere"] = (pkg.ManualScene(cam, tex, marg, cond, spheres=spheres), 32, 16, want)
+    nu, nv = 32, 16
+
+    def vertex(i, j):
+        th, ph = np.pi * j / nv, 2 * np.pi * i / nu
+        return (np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph))
+
+    tris = []
+    for j in range(nv):
+        for i in range(nu):
+            a, b, c, e = vertex(i, j), vertex(i + 1, j), vertex(i + 1, j + 1), vertex(i, j + 1)
+            if j > 0:
+                tris.append((a, b, c))                       # wound so that cross(v0 - v2, v1 - v2) points outwards
+            if j < nv - 1:
+                tris.append((a, c, e))
+    bvh = pkg.bvh_build(np.array(tris, dtype=np.float32))
+    for kind, typ, want in (("lambertian", pkg.DIFFUSE, rho * L), ("glossy", pkg.GLOSSY, (0.05 + 0.95 * rho) * L)):
+        cases[kind + " mesh"] = (pkg.ManualScene(cam, tex, marg, cond, bvh=bvh, mesh_material=mat, mesh_material_type=typ),
+                                 32, 16, want)
+    return cases
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

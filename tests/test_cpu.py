@@ -168,6 +168,19 @@ def test_oracle_reproduces_handworked_film(pkg):
         assert st.paths == W * H * spp and st.paths < st.rays <= 2 * st.paths
 
 
+def test_oracle_converges_to_radiometry(pkg):
+    """Films known from radiometry alone (tests/scenes.py::furnace_cases: a Lambertian plane under a non-uniform sky against
+    the float64 integral of L cos / pi; Lambertian, mirror and glossy convex bodies in a constant sky): the oracle's mean over
+    the film, 524,288 paths, is within 1 % (the statistical error is below 0.1 %; the rest is the reference's table-driven
+    light sampler).  A check of the estimator -- pdfs, the 50/50 mix, the 5 % glossy branch, normals of spheres and of mesh
+    triangles -- that is not one restatement agreeing with another."""
+    for name, (scene, W, H, want) in S.furnace_cases(pkg).items():
+        film, st = O.render(S.as_oracle_desc(scene), W, H, 0, 1024, 1024, seed=3, nthreads=8)
+        got = film.reshape(-1, 3).mean(axis=0, dtype=np.float64)
+        assert st.rays == 2 * st.paths, name                  # camera -> surface -> sky, nothing else
+        assert np.abs(got / want - 1).max() < 0.01, (name, got, want)
+
+
 def test_host_bvh_parallel_build_equals_serial(pkg):
     """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
     bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""
