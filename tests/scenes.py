@@ -540,7 +540,10 @@ def furnace_cases(pkg):
         rho / pi x the integral of L(w) w.y over the upper hemisphere, here taken in float64 on a 2048 x 8192 midpoint grid.
       the others: a constant sky L (64 x 32 texels, so the light sampler and its pdf are in play) around a unit sphere or a
         convex 960-triangle mesh: Lambertian rho L; mirror rho L (reference src/render.cu:195-211); glossy (0.05 + 0.95 rho) L,
-        the 5 % mirror branch leaving the throughput alone (src/render.cu:164-193).
+        the 5 % mirror branch leaving the throughput alone (src/render.cu:164-193); clear glass L.
+    Scenes with interreflection are left out on purpose: the reference's roulette divides a throughput above 1 by itself
+    without a matching survival probability (src/render.cu:78-86), so its multi-bounce films lose energy by design of the
+    reference (a white furnace of the README's spheres over a floor comes out at 0.78-0.99 L), and physics pins nothing there.
     The reference's estimator (one-sample mix of cosine and light sampling, src/render.cu:129-162) is unbiased up to its light
     sampler, which draws texel-grid directions from two quantile tables of W and H entries (src/environment_map.cu:107-125,
     src/environment_map.cuh:39-49): that costs up to 0.4 % here, so the tests allow 1 %."""
@@ -579,6 +582,10 @@ def furnace_cases(pkg):
                             ("glossy", pkg.GLOSSY, (0.05 + 0.95 * rho) * L)):
         spheres = [pkg.make_sphere((0, 0, 0), 1.0, mat, typ)]
         cases[kind + " sphere"] = (pkg.ManualScene(cam, tex, marg, cond, spheres=spheres), 32, 16, want)
+    # clear glass: every interaction multiplies the throughput by 1 (src/render.cu:213-242), the roulette's survival
+    # probability stays 1, and a path cut at the depth limit still collects the sky (src/render.cu:62-73): L whatever the path
+    spheres = [pkg.make_sphere((0, 0, 0), 1.0, (1.0, 1.0, 1.0, 1.5), pkg.GLASS)]
+    cases["clear glass sphere"] = (pkg.ManualScene(cam, tex, marg, cond, spheres=spheres), 32, 16, L)
     nu, nv = 32, 16
 
     def vertex(i, j):
