@@ -7,7 +7,7 @@ rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        kind = next((k for k in ("k_extend", "k_bounce", "k_generate", "k_film_reduce", "k_take", "k_advance", "k_tail") if k in n), None)
+        kind = next((k for k in ("k_extend", "k_path_stream", "k_bounce", "k_generate", "k_film_reduce", "k_take", "k_advance", "k_tail") if k in n), None)
         if kind:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, r["Stream_Id"]))
 rows.sort()
@@ -36,6 +36,6 @@ for st, rs in by_stream.items():
     print("stream", st)
     prev_end = None
     for s, e, k, _ in rs:
-        if k in ("k_extend", "k_film_reduce", "k_generate", "k_bounce", "k_tail"):
+        if k in ("k_extend", "k_path_stream", "k_film_reduce", "k_generate", "k_bounce", "k_tail"):
             print("  %-14s start %8.3f  dur %8.3f  gap before %7.3f" % (k, (s - t0) / 1e6, (e - s) / 1e6, 0 if prev_end is None else (s - prev_end) / 1e6))
         prev_end = e
