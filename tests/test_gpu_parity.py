@@ -1049,6 +1049,32 @@ def test_whole_path_kernel_slabs_partition_and_odd_sizes(pkg, ctx):
         ctx.set_option(pkg.OPT_SLAB_BYTES, 32 << 30)
 
 
+def test_scene_without_any_primitive(pkg, ctx):
+    """A scene file may hold a camera and an environment and nothing else: every camera ray leaves at once (one ray per path,
+    all settled where they are made), queries return misses, and the film is the oracle's in every render mode."""
+    cam = pkg.camera_make((0, 1, 5), (0, 0.5, 0), 35.0, 1.5, 0.1, 4.75)
+    tex, marg, cond = S.small_env(pkg)
+    scene = pkg.ManualScene(cam, tex, marg, cond)
+    W, H, spp = 48, 32, 8
+    want, ost = O.render(S.as_oracle_desc(scene), W, H, 0, spp, spp, seed=4)
+    assert ost.rays == ost.paths == W * H * spp
+    ctx.upload(scene)
+    org = np.zeros((65, 3), np.float32)
+    dir_ = np.tile(np.array([[0.0, 0.6, -0.8]], np.float32), (65, 1))
+    t, prim = ctx.intersect(org, dir_)[:2]
+    assert (prim == 0xFFFFFFFF).all() and (t == np.float32(3.402823466e38)).all()
+    ctx.film_bind(W, H)
+    try:
+        for mode in (1, 2, 0):
+            ctx.set_option(pkg.OPT_RENDER_MODE, mode)
+            ctx.film_clear()
+            st = ctx.render(0, spp, spp, seed=4)
+            assert_same_film(ctx.film_download(), want, "no primitives, mode %d" % mode)
+            assert st.rays == st.paths == W * H * spp and st.rays_escaped == st.rays
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
+
+
 def test_error_paths(pkg):
     c = pkg.Context(0)
     with pytest.raises(pkg.PtError):
