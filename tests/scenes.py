@@ -607,6 +607,21 @@ def furnace_cases(pkg):
     return cases
 
 
+def degenerate_mesh():
+    """The low-poly bunny with 5 % of its triangles made degenerate: two equal vertices, three vertices on a line, all three
+    equal.  The reference gives a triangle whose matrix is singular the identity as its transform (include/linear_math.cuh:
+    112-113 via src/bvh.cu:214-227): a phantom unit triangle in the plane z = 0 at the origin, reachable only through the
+    degenerate triangle's own (epsilon-padded) leaf box.  Returns (triangles, indices of the degenerate ones)."""
+    tris = golden_mesh("bunny_lowpoly").copy()
+    rng = np.random.default_rng(5)
+    idx = np.sort(rng.choice(len(tris), len(tris) // 20, replace=False))
+    tris[idx[::3], 1] = tris[idx[::3], 0]
+    tris[idx[1::3], 2] = tris[idx[1::3], 0] + (tris[idx[1::3], 1] - tris[idx[1::3], 0]) * np.float32(0.5)
+    tris[idx[2::3], 1] = tris[idx[2::3], 0]
+    tris[idx[2::3], 2] = tris[idx[2::3], 0]
+    return tris, idx
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

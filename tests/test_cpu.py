@@ -235,6 +235,23 @@ def test_host_bvh_degenerate_centroids(pkg):
     assert np.array_equal(a["tris"].view(np.uint32), b["tris"].view(np.uint32))
 
 
+def test_host_bvh_with_degenerate_triangles(pkg):
+    """Triangles without area (tests/scenes.py::degenerate_mesh): the builder gives them the identity transform like the
+    reference does, never a NaN or an infinity, byte for byte as the oracle."""
+    tris, idx = S.degenerate_mesh()
+    b = O.bvh_build(tris)
+    for threads in (1, 4):
+        a = pkg.bvh_build(tris, threads=threads)
+        for k in ("nodes", "tris", "prim_ids"):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (k, threads)
+    assert np.isfinite(b["tris"]).all()
+    rows = b["tris"][:b["num_tri_float4"]]
+    first = np.flatnonzero(np.isin(b["prim_ids"][:len(rows)], idx))
+    identity = np.array([[0, 0, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0]], np.float32)
+    singular = [i for i in first if np.array_equal(rows[i:i + 3], identity)]
+    assert len(singular) >= len(idx) * 2 // 3            # two equal vertices and three equal vertices are exactly singular
+
+
 def test_host_env_equals_oracle(pkg):
     tex, marg, cond = S.small_env(pkg, 64, 32)
     tex2 = tex.copy()

@@ -1075,6 +1075,49 @@ def test_scene_without_any_primitive(pkg, ctx):
         ctx.set_option(pkg.OPT_RENDER_MODE, 0)
 
 
+def test_mesh_with_degenerate_triangles_matches_oracle(pkg, ctx):
+    """Triangles without area get the identity transform from the reference's builder (tests/scenes.py::degenerate_mesh): a
+    phantom unit triangle at the origin behind each one's leaf box.  Rays aimed through that phantom at the degenerate
+    triangles find it where the reference's arithmetic says -- the device's hits are the oracle's, phantom hits included --
+    and a film of the mesh is the oracle's."""
+    tris, idx = S.degenerate_mesh()
+    bvh = pkg.bvh_build(tris)
+    cam = pkg.camera_make((0.2, 1.2, 3.5), (-0.1, 0.8, 0), 40.0, 1.5, 0.0, 3.5)
+    tex, marg, cond = S.small_env(pkg)
+    scene = pkg.ManualScene(cam, tex, marg, cond, bvh=bvh, mesh_material=(0.6, 0.6, 0.6, 0.0),
+                            mesh_material_type=pkg.DIFFUSE)
+    rng = np.random.default_rng(1)
+    n = 20000
+    target = tris[rng.choice(idx, n), 0].astype(np.float64)
+    uv = rng.uniform(0, 1, (n, 2))
+    uv = np.where((uv.sum(axis=1) > 1)[:, None], 1 - uv, uv)
+    through = np.concatenate([uv, np.zeros((n, 1))], axis=1)          # a point of the phantom triangle
+    d = target - through
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org = (through - 0.5 * d).astype(np.float32)
+    d = d.astype(np.float32)
+    desc = S.as_oracle_desc(scene)
+    ot, oprim, onrm, _ = O.intersect(desc, org, d, want_normals=True)
+    assert np.isin(oprim[oprim != 0xFFFFFFFF], idx).sum() > 100       # the phantoms are found
+    ctx.upload(scene)
+    t, prim, nrm = ctx.intersect(org, d, want_normals=True)[:3]
+    assert np.array_equal(prim, oprim) and np.array_equal(t, ot)
+    hit = oprim != 0xFFFFFFFF
+    assert np.array_equal(nrm[hit].view(np.uint32), onrm[hit].view(np.uint32))
+    W, H, spp = 96, 64, 8
+    want, ost = O.render(desc, W, H, 0, spp, spp, seed=6)
+    ctx.film_bind(W, H)
+    try:
+        for mode in (1, 2):
+            ctx.set_option(pkg.OPT_RENDER_MODE, mode)
+            ctx.film_clear()
+            st = ctx.render(0, spp, spp, seed=6)
+            assert_same_film(ctx.film_download(), want, "degenerate triangles, mode %d" % mode)
+            assert st.rays == ost.rays
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
+
+
 def test_error_paths(pkg):
     c = pkg.Context(0)
     with pytest.raises(pkg.PtError):
