@@ -1118,6 +1118,37 @@ def test_mesh_with_degenerate_triangles_matches_oracle(pkg, ctx):
         ctx.set_option(pkg.OPT_RENDER_MODE, 0)
 
 
+def test_hostile_rays_give_the_oracles_answers(pkg, ctx):
+    """Rays no renderer makes but a caller of the query entry point may pass: zero, axis-parallel, infinite and NaN
+    directions, origins at infinity, NaN or 1e30 away, not-normalised and denormal directions.  The traversal ends (it
+    visits a finite tree) and returns what the reference's arithmetic returns for them: the oracle's t, id and normal, bit
+    for bit, NaN for NaN."""
+    scene = S.parity_cases(pkg)["knot"]
+    base_o, base_d = O.primary_rays(S.as_oracle_desc(scene), 24, 16, sample=0, seed=8)
+    rng = np.random.default_rng(8)
+    specials = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 1e-42, 3e38], np.float32)
+    n = 4096
+    org = base_o[rng.integers(0, len(base_o), n)].copy()
+    d = base_d[rng.integers(0, len(base_d), n)].copy()
+    for arr in (org, d):
+        which = rng.random((n, 3)) < 0.35
+        arr[which] = specials[rng.integers(0, len(specials), which.sum())]
+    d[:8] = 0.0                                              # the zero direction, from eight origins
+    ctx.upload(scene)
+    ot, oprim, onrm, _ = O.intersect(S.as_oracle_desc(scene), org, d, want_normals=True)
+    for mode in (2, 1):
+        ctx.set_option(pkg.OPT_EXTEND_MODE, mode)
+        t, prim, nrm = ctx.intersect(org, d, want_normals=True)[:3]
+        assert np.array_equal(prim, oprim), mode
+        assert np.array_equal(t.view(np.uint32), ot.view(np.uint32)) or \
+            ((t.view(np.uint32) == ot.view(np.uint32)) | (np.isnan(t) & np.isnan(ot))).all(), mode
+        hit = oprim != 0xFFFFFFFF
+        same = (nrm[hit].view(np.uint32) == onrm[hit].view(np.uint32)) | (np.isnan(nrm[hit]) & np.isnan(onrm[hit]))
+        assert same.all(), mode
+    ctx.set_option(pkg.OPT_EXTEND_MODE, 2)
+    assert (oprim != 0xFFFFFFFF).sum() > 50                  # some of them do hit something
+
+
 def test_error_paths(pkg):
     c = pkg.Context(0)
     with pytest.raises(pkg.PtError):
