@@ -267,9 +267,52 @@ def test_host_env_equals_oracle(pkg):
     assert 0.8 < integral < 1.2
 
 
+def test_environment_tables_worked_out_by_hand(pkg):
+    """The importance-sampling tables of a 4 x 2 map, derived on paper from the reference's text (src/environment_map.cu:55-125),
+    not from either builder.  Grey texels of luminance L(x, y), distribution row y = 0 at the BOTTOM of the image
+    (data index (H - y - 1) W + x):  L = (1, 3), (3, 1), (1, 2), (6, 2) for x = 0..3, y = 0, 1.
+    Row weights sin((y + 0.5) pi / 2) are sin(pi / 4) for both rows and cancel.
+      conditional CDFs per column: (1/4, 1), (3/4, 1), (1/3, 1), (3/4, 1); column sums 4, 4, 3, 8 of 19
+      marginal CDF: 4/19, 8/19, 11/19, 1
+      marginal table, entry x = first i with cdf[i] >= (x + 1) / 4, i never going back: 1, 2, 3, 3
+      conditional tables, entry y = first i with cdf[i] >= (y + 1) / 2: (1, 1), (0, 1), (1, 1), (0, 1)
+      pdf (written into alpha): row y = 0 has sin(0) = 0 -> 0; row y = 1 has sin(pi / 2) = 1 ->
+        W H pdf_x pdf_y / (2 pi^2) with pdf_x = (4, 4, 3, 8) / 19 and pdf_y = cdf[1] - cdf[0] = 3/4, 1/4, 2/3, 1/4.
+    No comparison above is near a tie, so the integer tables must come out exactly; the pdfs within float rounding."""
+    L = np.array([[1, 3], [3, 1], [1, 2], [6, 2]], np.float32)               # [x][y]
+    W, H = 4, 2
+    want_marg = [1, 2, 3, 3]
+    want_cond = [1, 1, 0, 1, 1, 1, 0, 1]                                     # [x * H + y]
+    pdf_x = np.array([4, 4, 3, 8]) / 19.0
+    pdf_y1 = np.array([3 / 4, 1 / 4, 2 / 3, 1 / 4])
+    want_alpha = np.zeros((H, W))
+    want_alpha[0] = W * H * pdf_x * pdf_y1 / (2 * np.pi ** 2)                 # y = 1 is image row 0
+    for what, build in (("host", pkg.env_build), ("oracle", O.env_build)):
+        tex = np.zeros((H, W, 4), np.float32)
+        for x in range(W):
+            for y in range(H):
+                tex[H - 1 - y, x, :3] = L[x, y]
+        tex[..., 3] = 7.0                                                    # overwritten by the build
+        marg, cond = build(tex)
+        assert list(marg) == want_marg, what
+        assert list(cond) == want_cond, what
+        assert np.array_equal(tex[1, :, 3], np.zeros(W, np.float32)), what
+        assert np.allclose(tex[0, :, 3], want_alpha[0], rtol=2e-6, atol=0), (what, tex[0, :, 3], want_alpha[0])
+        assert np.array_equal(tex[..., :3].max(axis=2), L.T[::-1]), what     # the colours are left alone
+
+
 def test_host_camera_equals_oracle(pkg):
     for args in [((0, 1, 5), (0, 0.5, 0), 35.0, 16 / 9, 0.1, 4.75), ((-1.1, 0.2, -0.8), (0, 0, 0), 38.0, 1.5, 0.01, 1.15)]:
         assert bytes(pkg.camera_make(*args)) == bytes(O.camera_make(*args))
+    # and a frame that follows on paper from the reference's text (src/camera.cuh:21-37): at the origin looking down -z, 90
+    # degrees, aspect 2, focus distance 3, aperture 0.5: w = (0, 0, 1), u = (1, 0, 0), v = (0, 1, 0); the image plane at the
+    # focus distance is 2 tan(45 deg) 3 = 6 high and 12 wide: right = (12, 0, 0), up = (0, 6, 0), bottom left (-6, -3, -3)
+    for make in (pkg.camera_make, O.camera_make):
+        cam = make((0, 0, 0), (0, 0, -1), 90.0, 2.0, 0.5, 3.0)
+        got = [list(getattr(cam, f)) for f in ("origin", "bottom_left", "right", "up", "u", "v", "w")]
+        want = [[0, 0, 0], [-6, -3, -3], [12, 0, 0], [0, 6, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]]
+        assert np.allclose(got, want, rtol=0, atol=2e-6)
+        assert cam.lens_radius == 0.25
 
 
 def test_hdr_roundtrip_and_rgbe_decode(pkg, tmp_path):
