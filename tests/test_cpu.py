@@ -350,6 +350,12 @@ def test_tonemap_and_png(pkg, tmp_path):
     a = pkg.tonemap16(film)
     b = O.tonemap16(film)
     assert np.array_equal(a, b)
+    # known answers of 65535 (1 - exp(-exposure x))^(1 / gamma), truncated (reference src/image.cpp:12-16): black stays 0, a bright
+    # value saturates, and x = ln 2 / exposure gives 65535 * 0.5^(1 / 2.2) = 47823.6
+    known = np.array([[[0.0, 100.0, np.log(2.0) / 2.0]]], np.float32)
+    for tm in (pkg.tonemap16, O.tonemap16):
+        v = tm(known).reshape(3).astype(int)
+        assert v[0] == 0 and v[1] == 65535 and abs(v[2] - 47823) <= 1
     path = str(tmp_path / "o.png")
     pkg.png16_write(path, a)
     raw = open(path, "rb").read()
