@@ -622,6 +622,37 @@ def degenerate_mesh():
     return tris, idx
 
 
+def fresnel_case(pkg, W=32, H=16):
+    """A clear glass plane y = 0 (index 1.5) under a sky of colour A above the horizon and B below it, seen at 9 to 39 degrees
+    of elevation by a pinhole camera.  A camera ray is reflected with probability R = r0 + (1 - r0) (1 - cos)^5, r0 = ((1 -
+    eta) / (1 + eta))^2 = 0.04 (Schlick, reference src/material.cuh:34-39, chosen against one uniform number,
+    src/render.cu:213-242) and then sees A, else it is refracted, goes on below the plane and sees B; the throughput stays 1.
+    So a pixel converges to R A + (1 - R) B with R from 0.05 at the bottom of the film to 0.44 at its top -- known from optics
+    and the camera model (src/camera.cuh:39-53: u = (x + xi - 0.5) / (W - 1), rows counted from the bottom), averaged here over
+    the pixel's jitter square in float64.  Returns (scene, expected film (H, W, 3), |A - B|)."""
+    A = np.array([1.0, 0.5, 0.25])
+    B = np.array([0.25, 0.5, 1.0])
+    tex = np.zeros((32, 64, 4), dtype=np.float32)
+    tex[:16, :, :3] = A                                      # rows 0..15: directions above the horizon
+    tex[16:, :, :3] = B
+    marg, cond = pkg.env_build(tex)
+    cam = pkg.camera_make((0, 1, 0), (0, 0.55, -1), 30.0, W / H, 0.0, 1.0)
+    planes = [pkg.make_plane((0, 0, 0), (0, 1, 0), (1.0, 1.0, 1.0, 1.5), pkg.GLASS)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, planes=planes)
+    bl, right, up = (np.array(list(getattr(cam, f)), dtype=np.float64) for f in ("bottom_left", "right", "up"))
+    g = (np.arange(8) + 0.5) / 8 - 0.5
+    want = np.zeros((H, W, 3))
+    for y in range(H):
+        for x in range(W):
+            u = (x + g[None, :]) / (W - 1)
+            v = (y + g[:, None]) / (H - 1)
+            t = bl + u[..., None] * right + v[..., None] * up
+            cos = -t[..., 1] / np.linalg.norm(t, axis=-1)
+            R = (0.04 + 0.96 * (1 - cos) ** 5)[..., None]
+            want[H - 1 - y, x] = (R * A + (1 - R) * B).mean(axis=(0, 1))
+    return scene, want, float(np.abs(A - B).max())
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

@@ -132,6 +132,27 @@ def test_device_converges_to_radiometry(pkg, ctx):
         ctx.set_option(pkg.OPT_RENDER_MODE, 0)
 
 
+def test_device_follows_the_fresnel_curve(pkg, ctx):
+    """tests/scenes.py::fresnel_case: every pixel of the device's film of a glass plane between two sky colours, 16,384
+    samples each, is within 1.5 % of the colour difference of R A + (1 - R) B with Schlick's R at that pixel's elevation
+    (statistical error 0.4 %), and the film mean within 0.1 %, in both render modes."""
+    scene, want, span = S.fresnel_case(pkg)
+    H, W = want.shape[:2]
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    try:
+        for mode in (1, 2):
+            ctx.set_option(pkg.OPT_RENDER_MODE, mode)
+            ctx.film_clear()
+            st = ctx.render(0, 16384, 16384, seed=9)
+            film = ctx.film_download().astype(np.float64)
+            assert st.rays == 2 * st.paths, mode
+            assert np.abs(film - want).max() < 0.015 * span, (mode, np.abs(film - want).max() / span)
+            assert np.abs(film.mean(axis=(0, 1)) - want.mean(axis=(0, 1))).max() < 0.001 * span, mode
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
+
+
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
     """The loop-per-phase batch kernel and the persistent single-step kernel must agree bit for bit with the fixture."""
     scene = S.parity_cases(pkg)["knot"]
