@@ -183,14 +183,14 @@ def test_oracle_converges_to_radiometry(pkg):
 
 def test_oracle_follows_the_fresnel_curve(pkg):
     """tests/scenes.py::fresnel_case: a glass plane between two sky colours; the row means of the oracle's film (32,768
-    samples per row) follow Schlick's reflectance over the camera's elevations within 1 % of the colour difference, and R
-    does span 0.05 to 0.44 over the film."""
+    samples per row) follow Schlick's reflectance and Snell's refraction angle over the camera's elevations within 1 % of
+    the colour difference, and R does span 0.05 to 0.44 over the film."""
     scene, want, span = S.fresnel_case(pkg)
     H, W = want.shape[:2]
     film, st = O.render(S.as_oracle_desc(scene), W, H, 0, 1024, 1024, seed=2, nthreads=8)
     assert st.rays == 2 * st.paths
     assert np.abs(film.mean(axis=1, dtype=np.float64) - want.mean(axis=1)).max() < 0.01 * span
-    R = (want[..., 0] - 0.25) / 0.75
+    R = (want[..., 2] - 1.0) / (0.25 - 1.0)              # the blue channel is A's with R, B's with 1 - R
     assert R.min() < 0.06 and R.max() > 0.40
 
 
