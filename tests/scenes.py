@@ -623,25 +623,27 @@ def degenerate_mesh():
 
 
 def fresnel_case(pkg, W=32, H=16):
-    """A clear glass plane y = 0 (index 1.5) under a sky of colour A above the horizon and, below it, a colour B whose red
-    grows linearly with the angle from the zenith; seen at 9 to 39 degrees of elevation by a pinhole camera.  A camera ray is
+    """A clear glass plane y = 0 (index 1.5) under a sky of colour A above the horizon, whose green grows linearly with the
+    angle from the zenith, and, below it, a colour B whose red does; seen at 9 to 39 degrees of elevation by a pinhole camera.  A camera ray is
     reflected with probability R = r0 + (1 - r0) (1 - cos)^5, r0 = ((1 - eta) / (1 + eta))^2 = 0.04 (Schlick, reference
-    src/material.cuh:34-39, chosen against one uniform number, src/render.cu:213-242) and then sees A; else it is refracted
+    src/material.cuh:34-39, chosen against one uniform number, src/render.cu:213-242) and then sees A at the mirrored
+    angle (include/cutil_math.cuh:1289-1292); else it is refracted
     (src/material.cuh:26-32), goes on below the plane at the angle Snell's law gives, sin(theta_t) = sin(theta_i) / 1.5, and
-    sees B there; the throughput stays 1.  So a pixel converges to R A + (1 - R) B(theta_t), with R from 0.05 at the bottom of
+    sees B there; the throughput stays 1.  So a pixel converges to R A(theta_i) + (1 - R) B(theta_t), with R from 0.05 at the bottom of
     the film to 0.44 at its top and theta_t from 31 to 41 degrees -- known from optics and the camera model
     (src/camera.cuh:39-53: u = (x + xi - 0.5) / (W - 1), rows counted from the bottom), averaged here over the pixel's
     jitter square in float64.  A ray that went straight through instead would see a red lower by 0.15 to 0.3.
     The environment's rows hold B at their centres, and the bilinear lookup reproduces a function that is linear in the
     angle exactly between row centres (src/environment_map.cuh:32-37).
     Returns (scene, expected film (H, W, 3), the tolerance unit |A - B| = 0.75)."""
-    A = np.array([1.0, 0.5, 0.25])
+    def above(theta_norm):                                   # angle from +y over pi, 0 .. 0.5: green grows towards the horizon
+        return np.stack([np.ones_like(theta_norm), 0.5 + theta_norm, np.full_like(theta_norm, 0.25)], -1)
 
     def below(theta_norm):                                   # angle from +y over pi, 0.5 .. 1
         return np.stack([0.25 + 1.5 * (theta_norm - 0.5), np.full_like(theta_norm, 0.5), np.ones_like(theta_norm)], -1)
 
     tex = np.zeros((32, 64, 4), dtype=np.float32)
-    tex[:16, :, :3] = A                                      # rows 0..15: directions above the horizon
+    tex[:16, :, :3] = above((np.arange(16) + 0.5) / 32)[:, None, :]       # rows 0..15: directions above the horizon
     tex[16:, :, :3] = below((np.arange(16, 32) + 0.5) / 32)[:, None, :]
     marg, cond = pkg.env_build(tex)
     cam = pkg.camera_make((0, 1, 0), (0, 0.55, -1), 30.0, W / H, 0.0, 1.0)
@@ -658,8 +660,9 @@ def fresnel_case(pkg, W=32, H=16):
             cos_i = -t[..., 1] / np.linalg.norm(t, axis=-1)
             R = (0.04 + 0.96 * (1 - cos_i) ** 5)[..., None]
             cos_t = np.sqrt(1 - (1 - cos_i ** 2) / 1.5 ** 2)
+            seen_above = above(np.arccos(cos_i) / np.pi)      # mirrored: the angle from the zenith is the angle of incidence
             seen_below = below(np.arccos(-cos_t) / np.pi)
-            want[H - 1 - y, x] = (R * A + (1 - R) * seen_below).mean(axis=(0, 1))
+            want[H - 1 - y, x] = (R * seen_above + (1 - R) * seen_below).mean(axis=(0, 1))
     return scene, want, 0.75
 
 
