@@ -540,7 +540,8 @@ def furnace_cases(pkg):
         rho / pi x the integral of L(w) w.y over the upper hemisphere, here taken in float64 on a 2048 x 8192 midpoint grid.
       the others: a constant sky L (64 x 32 texels, so the light sampler and its pdf are in play) around a unit sphere or a
         convex 960-triangle mesh: Lambertian rho L; mirror rho L (reference src/render.cu:195-211); glossy (0.05 + 0.95 rho) L,
-        the 5 % mirror branch leaving the throughput alone (src/render.cu:164-193); clear glass L.
+        the 5 % mirror branch leaving the throughput alone (src/render.cu:164-193); clear glass L; and a camera between two
+        facing mirrors rho^8 L: the depth cut and the roulette.
     Scenes with interreflection are left out on purpose: the reference's roulette divides a throughput above 1 by itself
     without a matching survival probability (src/render.cu:78-86), so its multi-bounce films lose energy by design of the
     reference (a white furnace of the README's spheres over a floor comes out at 0.78-0.99 L), and physics pins nothing there.
@@ -586,6 +587,16 @@ def furnace_cases(pkg):
     # probability stays 1, and a path cut at the depth limit still collects the sky (src/render.cu:62-73): L whatever the path
     spheres = [pkg.make_sphere((0, 0, 0), 1.0, (1.0, 1.0, 1.0, 1.5), pkg.GLASS)]
     cases["clear glass sphere"] = (pkg.ManualScene(cam, tex, marg, cond, spheres=spheres), 32, 16, L)
+    # two facing mirrors, the camera between them: no ray gets out, every path is cut after its 8th hit (two depth increments
+    # per hit against a limit of 16, src/render.cu:9,62-73) and collects the sky there, with rho^8 left of its throughput; the
+    # roulette (from the second hit on, survival probability = largest channel <= 1, src/render.cu:78-86) does not change the
+    # mean.  The camera looks 11 to 51 degrees upwards: a ray within epsilon of parallel to a plane passes it by the
+    # reference's rule (|d.n| <= 0.001 is a miss, src/object.cuh:62-75), gets out and would add its larger throughput.
+    hall = [pkg.make_plane((0, 0, 0), (0, 1, 0), (0.9, 0.8, 0.5, 0.0), pkg.MIRROR),
+            pkg.make_plane((0, 2, 0), (0, -1, 0), (0.9, 0.8, 0.5, 0.0), pkg.MIRROR)]
+    cam_hall = pkg.camera_make((0, 1, 0), (0, 1.6, -1), 40.0, 2.0, 0.0, 1.0)       # elevations 11 to 51 degrees
+    cases["hall of mirrors"] = (pkg.ManualScene(cam_hall, tex, marg, cond, planes=hall), 32, 16,
+                                np.array([0.9, 0.8, 0.5]) ** 8 * L)
     nu, nv = 32, 16
 
     def vertex(i, j):
