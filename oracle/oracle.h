@@ -19,12 +19,19 @@
  * independent float64 brute force and against closest hits worked out by
  * hand (tests/scenes.py, handworked_hits); (4) the RGBE pixel decode against the
  * reference's own vendored reader (stb_image, compiled from the reference
- * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz).
+ * tree into oracle/_ref by `make ref`; frozen in tests/golden/hdr_decode.npz);
+ * (5) the shading estimator against radiometry and optics: films whose
+ * converged value is known in closed form or by float64 quadrature (a
+ * Lambertian plane under a non-uniform sky, convex Lambertian / mirror /
+ * glossy / clear-glass bodies in a constant sky, a camera between two mirrors,
+ * a glass plane whose pixels follow Schlick's reflectance and Snell's angle:
+ * tests/scenes.py furnace_cases, fresnel_case), a film, the environment
+ * lookup tables of a 4 x 2 map and a camera frame worked out by hand.
  * sin / cos / atan2 / acos / x^5 of the shading path are evaluated by fixed polynomial kernels (stated here and,
  * separately, in the device code) instead of a math library's, so that host and device take every random decision
  * alike; their error against double precision is held to 3 ulp by the tests.
  * Everything else on the device side
- * (visit order details, shading, environment lookup) is "parity unpinned":
+ * (visit order details, individual shading decisions, the texture filter) is "parity unpinned":
  * the reference ships no tests, fixtures or golden outputs for it and cannot
  * be built here (CUDA toolkit, cuRAND, inline PTX), so it is restated from
  * the source text alone.
