@@ -677,6 +677,49 @@ def fresnel_case(pkg, W=32, H=16):
     return scene, want, 0.75
 
 
+def shaded_sphere_case(pkg, W=32, H=16):
+    """A Lambertian unit sphere under a smooth sky that is symmetric about no axis, seen from (1.5, 1, 3.5): the pixel whose
+    centre ray meets the sphere at normal n converges to rho / pi x the integral of L(w) max(n.w, 0) over all directions,
+    taken here in float64 on a 256 x 512 midpoint grid.  Unlike the plane of furnace_cases this holds the orientation of the
+    environment map -- which texel a direction looks up (reference src/environment_map.cuh:32-37: column from atan2(z, x),
+    row from acos(y)) and which direction a sampled texel stands for (src/environment_map.cuh:39-49) -- and the sphere's
+    normal (src/object.cuh:39): the expected values vary from 0.54 to 0.84 over the film, a mirrored map or a flipped
+    normal would move them by tens of percent.  Returns (scene, expected film (H, W, 3))."""
+    def sky(d):
+        s = np.array([0.3, 0.8, 0.5]) / np.linalg.norm([0.3, 0.8, 0.5])
+        return 0.6 + 0.4 * d[..., 0] + 1.5 * np.maximum(d @ s, 0.0) ** 8
+
+    def dirs(theta, phi):
+        T, P = np.meshgrid(theta, phi, indexing="ij")
+        return np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], -1), T
+
+    tint = np.array([1.0, 0.7, 0.4])
+    rho = np.array([0.8, 0.5, 0.3])
+    EW, EH = 256, 128
+    d, _ = dirs((np.arange(EH) + 0.5) * np.pi / EH, ((np.arange(EW) + 0.5) / EW - 0.5) * 2 * np.pi)
+    tex = np.zeros((EH, EW, 4), dtype=np.float32)
+    tex[..., :3] = sky(d)[..., None] * tint
+    marg, cond = pkg.env_build(tex)
+    cam = pkg.camera_make((1.5, 1.0, 3.5), (0, 0, 0), 10.0, W / H, 0.0, 4.0)      # the whole film lies on the sphere
+    spheres = [pkg.make_sphere((0, 0, 0), 1.0, (0.8, 0.5, 0.3, 0.0), pkg.DIFFUSE)]
+    scene = pkg.ManualScene(cam, tex, marg, cond, spheres=spheres)
+    o = np.array(list(cam.origin), dtype=np.float64)
+    bl, right, up = (np.array(list(getattr(cam, f)), dtype=np.float64) for f in ("bottom_left", "right", "up"))
+    n = 256
+    qd, T = dirs((np.arange(n) + 0.5) * np.pi / n, (np.arange(2 * n) + 0.5) * np.pi / n)
+    qd = qd.reshape(-1, 3)
+    Lq = sky(qd) * (np.sin(T) * (np.pi / n) ** 2).reshape(-1)
+    want = np.zeros((H, W, 3))
+    for y in range(H):
+        for x in range(W):
+            t = bl + x / (W - 1) * right + y / (H - 1) * up        # the pixel's centre ray (src/camera.cuh:39-53)
+            dd = t / np.linalg.norm(t)
+            b = o @ dd
+            nrm = o + (-b - np.sqrt(b * b - (o @ o - 1.0))) * dd     # first intersection with the unit sphere = its normal
+            want[H - 1 - y, x] = rho * tint * (Lq * np.maximum(qd @ nrm, 0.0)).sum() / np.pi
+    return scene, want
+
+
 def as_oracle_desc(scene):
     """The same scene bytes viewed through the oracle's (identically laid out) descriptor type."""
     import oracle_lib

@@ -194,6 +194,19 @@ def test_oracle_follows_the_fresnel_curve(pkg):
     assert R.min() < 0.06 and R.max() > 0.40
 
 
+def test_oracle_shades_a_sphere_as_radiometry_says(pkg):
+    """tests/scenes.py::shaded_sphere_case: 4 x 4-pixel block means of the oracle's film (32,768 paths each) are within 1.5 %
+    of rho / pi x the cosine-weighted integral of the sky around each pixel's normal -- the orientation of the environment
+    map and the sphere's normals, against a float64 quadrature."""
+    scene, want = S.shaded_sphere_case(pkg)
+    H, W = want.shape[:2]
+    film, st = O.render(S.as_oracle_desc(scene), W, H, 0, 2048, 2048, seed=4, nthreads=8)
+    assert st.rays == 2 * st.paths
+    blocks = lambda a: a.reshape(H // 4, 4, W // 4, 4, 3).mean(axis=(1, 3), dtype=np.float64)
+    assert np.abs(blocks(film) / blocks(want) - 1).max() < 0.015
+    assert want[..., 0].max() / want[..., 0].min() > 1.5            # the film is far from flat
+
+
 def test_host_bvh_parallel_build_equals_serial(pkg):
     """A mesh large enough for the parallel path: ranges of >= 65,536 triangles are split with all threads (parallel
     bounds, histogram and an order-preserving parallel partition), the subtrees below are built and flattened as tasks."""

@@ -154,6 +154,28 @@ def test_device_follows_the_fresnel_curve(pkg, ctx):
         ctx.set_option(pkg.OPT_RENDER_MODE, 0)
 
 
+def test_device_shades_a_sphere_as_radiometry_says(pkg, ctx):
+    """tests/scenes.py::shaded_sphere_case: every pixel of the device's film (16,384 samples) is within 3 % and every 4 x 4
+    block within 1 % of rho / pi x the cosine-weighted integral of the sky around that pixel's normal, in both render
+    modes."""
+    scene, want = S.shaded_sphere_case(pkg)
+    H, W = want.shape[:2]
+    blocks = lambda a: a.reshape(H // 4, 4, W // 4, 4, 3).mean(axis=(1, 3), dtype=np.float64)
+    ctx.upload(scene)
+    ctx.film_bind(W, H)
+    try:
+        for mode in (1, 2):
+            ctx.set_option(pkg.OPT_RENDER_MODE, mode)
+            ctx.film_clear()
+            st = ctx.render(0, 16384, 16384, seed=11)
+            film = ctx.film_download().astype(np.float64)
+            assert st.rays == 2 * st.paths, mode
+            assert np.abs(film / want - 1).max() < 0.03, (mode, np.abs(film / want - 1).max())
+            assert np.abs(blocks(film) / blocks(want) - 1).max() < 0.01, (mode, np.abs(blocks(film) / blocks(want) - 1).max())
+    finally:
+        ctx.set_option(pkg.OPT_RENDER_MODE, 0)
+
+
 def test_both_extend_kernels_give_identical_hits(pkg, ctx):
     """The loop-per-phase batch kernel and the persistent single-step kernel must agree bit for bit with the fixture."""
     scene = S.parity_cases(pkg)["knot"]
