@@ -341,6 +341,36 @@ def test_host_camera_equals_oracle(pkg):
         assert cam.lens_radius == 0.25
 
 
+def test_thin_lens_rays_meet_on_the_focal_plane(pkg):
+    """What a thin lens does, not how the reference writes it (src/camera.cuh:39-53): with the aperture open, the ray of a
+    film position starts somewhere on the lens disc and passes through the same point of the focal plane as the pinhole ray
+    of that position.  The oracle's camera rays with aperture 0.3 and with aperture 0 (same seed, so the same jitter) meet
+    there; the lens origins fill a disc of radius 0.15 in the lens plane evenly (mean 0, mean r^2 = R^2 / 2)."""
+    W, H = 48, 32
+    pos, look, focus = np.array([0.5, 1.0, 4.0]), np.array([0.0, 0.5, 0.0]), 3.0
+    tex, marg, cond = S.small_env(pkg)
+    rays = {}
+    for aperture in (0.0, 0.3):
+        cam = pkg.camera_make(tuple(pos), tuple(look), 35.0, W / H, aperture, focus)
+        scene = pkg.ManualScene(cam, tex, marg, cond)
+        rays[aperture] = tuple(a.astype(np.float64) for a in O.primary_rays(S.as_oracle_desc(scene), W, H, sample=3, seed=5))
+    axis = (look - pos) / np.linalg.norm(look - pos)
+
+    def on_focal_plane(org, d):
+        t = (focus - (org - pos) @ axis) / (d @ axis)
+        return org + d * t[:, None]
+
+    (o0, d0), (o1, d1) = rays[0.0], rays[0.3]
+    assert np.abs(o0 - pos).max() < 1e-6                                  # the pinhole
+    assert np.abs(on_focal_plane(o0, d0) - on_focal_plane(o1, d1)).max() < 2e-5
+    off = o1 - pos
+    assert np.abs(off @ axis).max() < 1e-6                                # origins lie in the lens plane
+    r2 = (off ** 2).sum(axis=1)
+    assert r2.max() <= 0.15 ** 2 * (1 + 1e-5)
+    assert abs(r2.mean() / (0.15 ** 2 / 2) - 1) < 0.06 and np.abs(off.mean(axis=0)).max() < 0.01
+    assert np.abs(np.linalg.norm(d1, axis=1) - 1).max() < 1e-6
+
+
 def test_hdr_roundtrip_and_rgbe_decode(pkg, tmp_path):
     rng = np.random.default_rng(1)
     img = (rng.random((16, 40, 3)) ** 4 * 100).astype(np.float32)
